@@ -1,0 +1,183 @@
+"""Pin the CPU oracle (oracle/p1_oracle.py) to the reference.
+
+Every golden vector under tests/golden/ was produced by importing the reference
+(tests/golden/make_golden.py); the known-answer checks restate the reference's
+own tests (reference tests/test_fem.py:85-179) against the oracle.
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+
+from oracle import p1_oracle as orc
+from _util import golden, golden_names, golden_json, rel_err, loss_grad
+
+
+def _mesh(g):
+    return g["nodes"], g["elements"], g["bc_nodes"], g["bc_vals"]
+
+
+@pytest.mark.parametrize("name", ["g1_config1"] + golden_names("g2_1d_fwd_") + ["g4_2d_fwd_32"])
+def test_forward_matches_reference(name):
+    g = golden(name)
+    u = orc.solve(*_mesh(g), g["kappa"], g["f"], sparse=False)
+    assert rel_err(u, g["u"]) < 1e-12
+    us = orc.solve(*_mesh(g), g["kappa"], g["f"], sparse=True)
+    assert rel_err(us, g["u"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", golden_names("g3_1d_grad_") + golden_names("g4_2d_0"))
+def test_adjoint_matches_reference_autograd(name):
+    g = golden(name)
+    kind = str(g["loss_kind"])
+    data = g["data"] if "data" in g else None
+    for sparse in (False, True):
+        u, dk, df = orc.solve_with_adjoint(*_mesh(g), g["kappa"], g["f"],
+                                           lambda u: loss_grad(kind, u, data), sparse=sparse)
+        assert rel_err(u, g["u"]) < 1e-11
+        assert abs(dk.sum() - g["dkappa"]) <= 1e-11 * max(abs(g["dkappa"]), 1e-300)
+        assert rel_err(df, g["df"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", golden_names("g5_asm_"))
+def test_assembled_system_matches_reference(name):
+    g = golden(name)
+    K, F = orc.assemble_dense(g["nodes"], g["elements"], g["kappa"], g["f"])
+    assert np.max(np.abs(K - g["K"])) < 1e-13 * np.max(np.abs(g["K"]))
+    assert np.max(np.abs(F - g["F"])) < 1e-14
+    Ks, Fs = orc.assemble_sparse(g["nodes"], g["elements"], g["kappa"], g["f"])
+    assert np.max(np.abs(Ks.toarray() - g["K"])) < 1e-13 * np.max(np.abs(g["K"]))
+    assert np.max(np.abs(Fs - g["F"])) < 1e-14
+
+
+def test_mesh_factories_match_reference_verbatim():
+    cases = {
+        "line_10": orc.mesh_line(10),
+        "line_7_shift": orc.mesh_line(7, -1.0, 2.5, 0.25, None),
+        "rect_4_4": orc.mesh_rectangle(4, 4),
+        "rect_3_2": orc.mesh_rectangle(3, 2, (0.0, 3.0), (0.0, 1.0), 0.5),
+    }
+    for name, (nodes, elements, bc_nodes, bc_vals) in cases.items():
+        g = golden("g6_mesh_" + name)
+        assert np.array_equal(nodes, g["nodes"]), name
+        assert np.array_equal(elements, g["elements"]), name
+        assert np.array_equal(bc_nodes, g["bc_nodes"]), name
+        assert np.array_equal(bc_vals, g["bc_vals"]), name
+        assert np.array_equal(orc.free_nodes(len(nodes), bc_nodes), g["free"]), name
+
+
+def test_mesh_factories_match_reference_sha256():
+    pins = golden_json("g6_mesh_sha256.json")
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    for key, pin in pins.items():
+        kind, *dims = key.split("_")
+        mesh = orc.mesh_line(int(dims[0])) if kind == "line" else orc.mesh_rectangle(int(dims[0]), int(dims[1]))
+        nodes, elements, bc_nodes, _ = mesh
+        assert sha(nodes) == pin["nodes"], key
+        assert sha(elements) == pin["elements"], key
+        assert sha(bc_nodes) == pin["bc_nodes"], key
+        assert len(bc_nodes) == pin["n_bc"], key
+
+
+@pytest.mark.parametrize("name", golden_names("g9_batch_"))
+def test_batched_semantics_is_loop_of_reference_solves(name):
+    g = golden(name)
+    u = orc.solve_batch(*_mesh(g), g["kappa"], g["f"])
+    assert rel_err(u, g["u"]) < 1e-12
+    dks = []
+    for b in range(len(g["kappa"])):
+        _, dk, df = orc.solve_with_adjoint(*_mesh(g), g["kappa"][b], g["f"][b], lambda u: 2 * u)
+        dks.append(dk.sum())
+        assert rel_err(df, g["df"][b]) < 1e-11
+    assert rel_err(np.array(dks), g["dkappa"]) < 1e-11
+    assert abs(sum(dks) - g["dkappa_sum"]) < 1e-11 * abs(g["dkappa_sum"])
+
+
+def test_physics_loss_values():
+    g = golden("g8_physics_loss")
+    fm = orc.physics_loss_fem_match(*_mesh(g), 1.0, g["f"], g["u_pred"])
+    va = orc.physics_loss_variational(g["nodes"], g["bc_nodes"], g["f"], g["u_pred"])
+    assert abs(fm - g["fem_match"]) < 1e-15
+    assert abs(va - g["variational"]) < 1e-13
+
+
+# --- known-answer tests restated from the reference's own suite --------------------
+
+def test_kat_1d_exact_quadratic():
+    """reference tests/test_fem.py:85-104: -u''=1 -> x(1-x)/2 at the nodes."""
+    for N, atol in ((10, 1e-10), (100, 1e-9)):
+        nodes, el, bn, bv = orc.mesh_line(N)
+        u = orc.solve(nodes, el, bn, bv, 1.0, np.ones(N + 1))
+        x = nodes[:, 0]
+        assert np.max(np.abs(u - x * (1 - x) / 2)) < atol
+        assert abs(u[0]) < 1e-12 and abs(u[-1]) < 1e-12      # test_fem.py:106-112
+
+
+def test_kat_1d_sinusoid_convergence():
+    """reference tests/test_fem.py:114-132: error ratio > 3 per refinement."""
+    errs = []
+    for N in (10, 20, 40, 80):
+        nodes, el, bn, bv = orc.mesh_line(N)
+        x = nodes[:, 0]
+        u = orc.solve(nodes, el, bn, bv, 1.0, math.pi ** 2 * np.sin(math.pi * x))
+        errs.append(np.max(np.abs(u - np.sin(math.pi * x))))
+    for a, b in zip(errs, errs[1:]):
+        assert a / (b + 1e-15) > 3.0
+
+
+def test_kat_1d_nonzero_dirichlet():
+    """reference tests/test_fem.py:134-142: f=0, u(0)=1, u(1)=2 -> 1+x."""
+    nodes, el, bn, bv = orc.mesh_line(10, bc_left=1.0, bc_right=2.0)
+    u = orc.solve(nodes, el, bn, bv, 1.0, np.zeros(11))
+    assert np.max(np.abs(u - (1 + nodes[:, 0]))) < 1e-10
+
+
+def test_kat_kappa_gradient_value():
+    """reference tests/test_fem.py:144-155 checks existence; SURVEY 8(a13) pins the
+    value: N=5, kappa=1.5, f=1, L=sum(u): dL/dkappa = -0.17777777777777773."""
+    nodes, el, bn, bv = orc.mesh_line(5)
+    u, dk, df = orc.solve_with_adjoint(nodes, el, bn, bv, 1.5, np.ones(6), lambda u: np.ones_like(u))
+    assert abs(dk.sum() - (-0.17777777777777773)) < 1e-15
+    assert np.allclose(df, [0, 0.16 / 3, 0.08, 0.08, 0.16 / 3, 0], atol=1e-15)
+
+
+def test_kat_2d_values():
+    """SURVEY 8(c) captured values: 2D 4x4 kappa=1 f=1 free-node solution;
+    reference tests/test_fem.py:163-179 (f=0 -> 0; f=1 -> positive interior)."""
+    nodes, el, bn, bv = orc.mesh_rectangle(4, 4)
+    u = orc.solve(nodes, el, bn, bv, 1.0, np.ones(25))
+    free = orc.free_nodes(25, bn)
+    expect = [0.04296875, 0.0546875, 0.04296875, 0.0546875, 0.0703125, 0.0546875,
+              0.04296875, 0.0546875, 0.04296875]
+    assert np.max(np.abs(u[free] - expect)) < 1e-16
+    assert np.max(np.abs(orc.solve(nodes, el, bn, bv, 1.0, np.zeros(25)))) < 1e-10
+    nodes, el, bn, bv = orc.mesh_rectangle(8, 8)
+    u = orc.solve(nodes, el, bn, bv, 1.0, np.ones(81))
+    assert u[orc.free_nodes(81, bn)].min() > 0.0
+
+
+def test_kappa_recovery_trajectory():
+    """examples/poisson_1d_demo.py:88-112 through the oracle's explicit adjoint:
+    loss / grad / kappa at every Adam step match the reference run (G7)."""
+    import torch
+    g = golden("g7_kappa_recovery")
+    nodes, el, bn, bv = _mesh(g)
+    k = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([k], lr=0.1)
+    for step in range(200):
+        opt.zero_grad()
+        kv = abs(float(k.detach()))
+        u, dk, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kv, g["f"],
+                                          lambda u: 2 * (u - g["u_data"]) / u.size)
+        loss = float(np.mean((u - g["u_data"]) ** 2))
+        k.grad = torch.tensor(dk.sum() * np.sign(float(k)), dtype=torch.float64)
+        opt.step()
+        if step in (0, 1, 2, 99, 199):
+            ref = g["traj"][step]
+            assert abs(loss - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-20
+            assert abs(float(k) - ref[2]) < 1e-9
+    assert abs(float(k) - 2.0) < 1e-4
