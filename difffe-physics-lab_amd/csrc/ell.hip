@@ -1,0 +1,624 @@
+// General P1 path (any 1D/2D mesh): element integrals, assembly into a batch-shared ELL
+// pattern, Dirichlet elimination, batched Jacobi-PCG, gradient contraction, layout changes.
+//
+// Data layout: node-major, batch-innermost (n, Bp): entry (i, b) at i*Bp + b.  A wave's 64
+// lanes are 64 samples of one node (Bp >= 64), so every load -- including the ELL "gather"
+// p[col] -- is one contiguous 512 B segment, column indices are wave-uniform and amortised
+// over the batch, and per-sample dot products are per-lane sums with no cross-lane traffic.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace {
+
+using namespace diffhe;
+
+typedef long long i64;
+
+// ---------------------------------------------------------------------------------------
+// Element integrals (reference solver.py:84-88 1D, solver.py:119-139 2D)
+// ---------------------------------------------------------------------------------------
+__device__ inline void tri_integrals(double xi, double yi, double xj, double yj, double xk, double yk, double* k0,
+                                     double* area_out) {
+  const double area = 0.5 * fabs((xj - xi) * (yk - yi) - (xk - xi) * (yj - yi));  // solver.py:119
+  const double bb[3] = {yj - yk, yk - yi, yi - yj};                               // solver.py:125-129
+  const double cc[3] = {xk - xj, xi - xk, xj - xi};                               // solver.py:130-134
+  const bool keep = !(area < 1e-15);                                              // solver.py:120-121
+  const double inv = keep ? 1.0 / (4.0 * area) : 0.0;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) k0[p * 3 + q] = keep ? (bb[p] * bb[q] + cc[p] * cc[q]) * inv : 0.0;
+  *area_out = keep ? area : 0.0;
+}
+
+__global__ __launch_bounds__(256) void element_integrals_kernel(const double* __restrict__ coords,
+                                                                 const int* __restrict__ elems, int dim, int n, int m,
+                                                                 double* __restrict__ k0, double* __restrict__ m0) {
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (i64)gridDim.x * blockDim.x) {
+    if (dim == 1) {
+      const int i = elems[e], j = elems[(i64)m + e];
+      const double h = coords[j] - coords[i];
+      const double k = 1.0 / h;
+      k0[e] = k; k0[(i64)m + e] = -k; k0[2 * (i64)m + e] = -k; k0[3 * (i64)m + e] = k;
+      m0[e] = 0.5 * h; m0[(i64)m + e] = 0.0; m0[2 * (i64)m + e] = 0.0; m0[3 * (i64)m + e] = 0.5 * h;
+    } else {
+      const int i = elems[e], j = elems[(i64)m + e], k = elems[2 * (i64)m + e];
+      double loc[9], area;
+      tri_integrals(coords[i], coords[(i64)n + i], coords[j], coords[(i64)n + j], coords[k], coords[(i64)n + k], loc,
+                    &area);
+#pragma unroll
+      for (int pq = 0; pq < 9; ++pq) {
+        k0[(i64)pq * m + e] = loc[pq];
+        m0[(i64)pq * m + e] = area / 9.0;  // F_p += area/3 * (f_i+f_j+f_k)/3, solver.py:143-145
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Deterministic row-gather assembly + Dirichlet elimination
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_rows_kernel(
+    const double* __restrict__ local, const double* __restrict__ kappa, i64 kse, i64 ksb,
+    const int* __restrict__ ent_ptr, const int* __restrict__ contrib, const int* __restrict__ cols,
+    const unsigned char* __restrict__ is_bc, const double* __restrict__ g, double* __restrict__ vals,
+    double* __restrict__ lift, int n, int m, int W, int Bv) {
+  const NodeMap nm = node_map(Bv);
+  if (nm.b >= Bv) return;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const bool row_bc = is_bc && is_bc[i];
+    double lf = 0.0;
+    for (int k = 0; k < W; ++k) {
+      const i64 ent = (i64)k * n + i;
+      const int c0 = ent_ptr[ent], c1 = ent_ptr[ent + 1];
+      double v = 0.0;
+      for (int c = c0; c < c1; ++c) {
+        const int code = contrib[c];
+        const int e = code >> 4, pq = code & 15;
+        const double kap = kappa ? kappa[(i64)e * kse + (i64)nm.b * ksb] : 1.0;
+        v += kap * local[(i64)pq * m + e];  // K[p,q] += kappa * k0[p,q], solver.py:89-92/:137-140
+      }
+      if (is_bc) {
+        const int j = cols[ent];
+        if (row_bc) {
+          v = (k == 0) ? 1.0 : 0.0;
+        } else if (j != i && is_bc[j]) {
+          lf += v * g[j];  // F_free -= K[free,bc] g, solver.py:166-169
+          v = 0.0;
+        }
+      }
+      vals[ent * Bv + nm.b] = v;
+    }
+    if (lift) lift[(i64)i * Bv + nm.b] = lf;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Element-parallel assembly with fp64 atomics; element integrals staged in LDS
+// ---------------------------------------------------------------------------------------
+constexpr int kElemTile = 64;
+
+__global__ __launch_bounds__(256) void assemble_atomic_kernel(const double* __restrict__ coords,
+                                                               const int* __restrict__ elems, int dim,
+                                                               const double* __restrict__ kappa, i64 kse, i64 ksb,
+                                                               const int* __restrict__ slot_of,
+                                                               double* __restrict__ vals, int n, int m, int Bp) {
+  __shared__ double k0s[9][kElemTile];
+  __shared__ int rows[3][kElemTile];
+  const int npe = dim + 1, nloc = npe * npe;
+  const int LB = Bp < kWave ? Bp : kWave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y * kWave + (lane % LB);
+  const int sub = lane / LB, nsub = kWave / LB;
+  for (i64 base = (i64)blockIdx.x * kElemTile; base < m; base += (i64)gridDim.x * kElemTile) {
+    __syncthreads();
+    if (threadIdx.x < kElemTile && base + threadIdx.x < m) {
+      const i64 e = base + threadIdx.x;
+      const int t = threadIdx.x;
+      if (dim == 1) {
+        const int i = elems[e], j = elems[(i64)m + e];
+        const double k = 1.0 / (coords[j] - coords[i]);
+        k0s[0][t] = k; k0s[1][t] = -k; k0s[2][t] = -k; k0s[3][t] = k;
+        rows[0][t] = i; rows[1][t] = j;
+      } else {
+        const int i = elems[e], j = elems[(i64)m + e], k = elems[2 * (i64)m + e];
+        double loc[9], area;
+        tri_integrals(coords[i], coords[(i64)n + i], coords[j], coords[(i64)n + j], coords[k], coords[(i64)n + k],
+                      loc, &area);
+#pragma unroll
+        for (int pq = 0; pq < 9; ++pq) k0s[pq][t] = loc[pq];
+        rows[0][t] = i; rows[1][t] = j; rows[2][t] = k;
+      }
+    }
+    __syncthreads();
+    if (b >= Bp) continue;
+    for (int el = wave * nsub + sub; el < kElemTile && base + el < m; el += 4 * nsub) {
+      const i64 e = base + el;
+      const double kap = kappa ? kappa[e * kse + (i64)b * ksb] : 1.0;
+      for (int pq = 0; pq < nloc; ++pq) {
+        const int slot = slot_of[(i64)pq * m + e];
+        const int row = rows[pq / npe][el];
+        unsafeAtomicAdd(&vals[((i64)slot * n + row) * Bp + b], kap * k0s[pq][el]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void apply_dirichlet_kernel(const int* __restrict__ cols,
+                                                               const unsigned char* __restrict__ is_bc,
+                                                               const double* __restrict__ g, double* __restrict__ vals,
+                                                               double* __restrict__ F, int n, int W, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const bool row_bc = is_bc[i];
+    double lf = 0.0;
+    for (int k = 0; k < W; ++k) {
+      const i64 ent = (i64)k * n + i;
+      const int j = cols[ent];
+      if (row_bc) {
+        vals[ent * Bp + nm.b] = (k == 0) ? 1.0 : 0.0;
+      } else if (j != i && is_bc[j]) {
+        lf += vals[ent * Bp + nm.b] * g[j];
+        vals[ent * Bp + nm.b] = 0.0;
+      }
+    }
+    if (F) F[(i64)i * Bp + nm.b] = row_bc ? 0.0 : F[(i64)i * Bp + nm.b] - lf;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// y = (is_bc ? 0 : M x - sub), M batch-shared ELL.  Load vector and df = M^T lambda.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restrict__ vals,
+                                                           const int* __restrict__ cols, const double* __restrict__ x,
+                                                           const double* __restrict__ sub, int sub_B,
+                                                           const unsigned char* __restrict__ is_bc,
+                                                           double* __restrict__ y, int n, int W, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    double acc = 0.0;
+    for (int k = 0; k < W; ++k) {
+      const i64 ent = (i64)k * n + i;
+      acc += vals[ent] * x[(i64)cols[ent] * Bp + nm.b];
+    }
+    if (sub) acc -= sub[(i64)i * sub_B + (sub_B == 1 ? 0 : nm.b)];
+    if (is_bc && is_bc[i]) acc = 0.0;
+    y[(i64)i * Bp + nm.b] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Batched Jacobi-PCG
+// ---------------------------------------------------------------------------------------
+struct CgScalars {  // each (Bp) doubles, in `work` after the vectors and partials
+  double *rz, *pAp, *alpha, *beta, *bb, *tol2, *rr;
+  int* active;    // (Bp)
+  int* iters;     // (Bp)
+  int* n_active;  // (1)
+};
+
+__global__ __launch_bounds__(256) void cg_init_kernel(const double* __restrict__ vals, const double* __restrict__ bvec,
+                                                       double* __restrict__ x, double* __restrict__ r,
+                                                       double* __restrict__ z, double* __restrict__ p,
+                                                       double* __restrict__ part_rz, double* __restrict__ part_bb, int n,
+                                                       int Bp, int Bv) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s_rz = 0.0, s_bb = 0.0;
+  if (ok)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const i64 o = (i64)i * Bp + nm.b;
+      const double bi = bvec[o];
+      const double zi = bi / vals[(i64)i * Bv + vb];  // slot 0 = diagonal
+      x[o] = 0.0; r[o] = bi; z[o] = zi; p[o] = zi;
+      s_rz += bi * zi;
+      s_bb += bi * bi;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t_rz = block_sum_per_sample(s_rz, Bp, lds);
+  const double t_bb = block_sum_per_sample(s_bb, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) {
+    part_rz[(i64)blockIdx.x * Bp + nm.b] = t_rz;
+    part_bb[(i64)blockIdx.x * Bp + nm.b] = t_bb;
+  }
+}
+
+__global__ __launch_bounds__(256) void cg_spmv_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
+                                                       const double* __restrict__ p, double* __restrict__ Ap,
+                                                       double* __restrict__ part_pAp, int n, int W, int Bp, int Bv) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  if (ok)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      double acc = 0.0;
+      for (int k = 0; k < W; ++k) {
+        const i64 ent = (i64)k * n + i;
+        acc += vals[ent * Bv + vb] * p[(i64)cols[ent] * Bp + nm.b];
+      }
+      const i64 o = (i64)i * Bp + nm.b;
+      Ap[o] = acc;
+      s += acc * p[o];
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t = block_sum_per_sample(s, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_pAp[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+__global__ __launch_bounds__(256) void cg_update_kernel(const double* __restrict__ vals, const double* __restrict__ p,
+                                                         const double* __restrict__ Ap, const double* __restrict__ alpha,
+                                                         double* __restrict__ x, double* __restrict__ r,
+                                                         double* __restrict__ z, double* __restrict__ part_rz,
+                                                         double* __restrict__ part_rr, int n, int Bp, int Bv) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s_rz = 0.0, s_rr = 0.0;
+  if (ok) {
+    const double a = alpha[nm.b];
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const i64 o = (i64)i * Bp + nm.b;
+      x[o] += a * p[o];
+      const double ri = r[o] - a * Ap[o];
+      const double zi = ri / vals[(i64)i * Bv + vb];
+      r[o] = ri; z[o] = zi;
+      s_rz += ri * zi;
+      s_rr += ri * ri;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t_rz = block_sum_per_sample(s_rz, Bp, lds);
+  const double t_rr = block_sum_per_sample(s_rr, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) {
+    part_rz[(i64)blockIdx.x * Bp + nm.b] = t_rz;
+    part_rr[(i64)blockIdx.x * Bp + nm.b] = t_rr;
+  }
+}
+
+__global__ __launch_bounds__(256) void cg_update_p_kernel(const double* __restrict__ z, const double* __restrict__ beta,
+                                                           double* __restrict__ p, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  const double be = beta[nm.b];
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    p[o] = z[o] + be * p[o];
+  }
+}
+
+// true residual |b - A x|^2 partials
+__global__ __launch_bounds__(256) void residual_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
+                                                        const double* __restrict__ bvec, const double* __restrict__ x,
+                                                        double* __restrict__ part, int n, int W, int Bp, int Bv) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  if (ok)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      double acc = bvec[(i64)i * Bp + nm.b];
+      for (int k = 0; k < W; ++k) {
+        const i64 ent = (i64)k * n + i;
+        acc -= vals[ent * Bv + vb] * x[(i64)cols[ent] * Bp + nm.b];
+      }
+      s += acc * acc;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t = block_sum_per_sample(s, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+// Sum the block partials of one quantity for sample b (fixed order: deterministic).
+// Block = 4 waves: lanes over samples, waves over quarters of the partial list.
+__device__ inline double sum_partials(const double* __restrict__ part, int nblk, int Bp, int b, double* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s = 0.0;
+  if (b < Bp)
+    for (int k = wave; k < nblk; k += 4) s += part[(i64)k * Bp + b];
+  lds[wave * kWave + lane] = s;
+  __syncthreads();
+  const double t = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
+  __syncthreads();
+  return t;
+}
+
+enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3 };
+
+__global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double* __restrict__ partA,
+                                                         const double* __restrict__ partB, int nblk, int Bp,
+                                                         double tol, CgScalars S, double* __restrict__ relres) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWave + lane;
+  const double a = sum_partials(partA, nblk, Bp, b, lds);
+  const double c = partB ? sum_partials(partB, nblk, Bp, b, lds) : 0.0;
+  if (wave != 0 || b >= Bp) return;
+  if (phase == PH_INIT) {  // a = r.z, c = b.b
+    S.rz[b] = a;
+    S.bb[b] = c;
+    S.tol2[b] = tol * tol * c;
+    S.active[b] = c > 0.0 ? 1 : 0;
+    S.iters[b] = 0;
+    S.alpha[b] = 0.0;
+    S.beta[b] = 0.0;
+  } else if (phase == PH_ALPHA) {  // a = p.Ap
+    S.alpha[b] = (S.active[b] && a > 0.0) ? S.rz[b] / a : 0.0;
+    if (b == 0) *S.n_active = 0;
+  } else if (phase == PH_BETA) {  // a = r.z (new), c = r.r
+    if (S.active[b]) {
+      S.iters[b] += 1;
+      S.rr[b] = c;
+      if (c <= S.tol2[b]) {
+        S.active[b] = 0;
+        S.beta[b] = 0.0;
+      } else {
+        S.beta[b] = a / S.rz[b];
+        S.rz[b] = a;
+        atomicAdd(S.n_active, 1);
+      }
+    } else {
+      S.beta[b] = 0.0;
+    }
+  } else {  // PH_RELRES: a = |b - A x|^2
+    relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// dL/dkappa contraction
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_kappa_kernel(const int* __restrict__ elems, const double* __restrict__ k0,
+                                                          const double* __restrict__ lam, const double* __restrict__ u,
+                                                          const double* __restrict__ g, int npe, int m, int Bp,
+                                                          double* __restrict__ dk_e,
+                                                          double* __restrict__ dk_part) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);  // "nodes" are elements here
+  const bool ok = nm.b < Bp;
+  double s = 0.0;
+  if (ok)
+    for (int e = nm.node0; e < m; e += nm.stride) {
+      double le[3], ue[3];
+      for (int p = 0; p < npe; ++p) {
+        const int node = elems[(i64)p * m + e];
+        const i64 o = (i64)node * Bp + nm.b;
+        le[p] = lam[o];
+        ue[p] = u[o] + (g ? g[node] : 0.0);  // full u: Dirichlet values included (Appendix A step 2)
+      }
+      double acc = 0.0;
+      for (int p = 0; p < npe; ++p)
+        for (int q = 0; q < npe; ++q) acc += le[p] * k0[(i64)(p * npe + q) * m + e] * ue[q];
+      const double dk = -acc;
+      if (dk_e) dk_e[(i64)e * Bp + nm.b] = dk;
+      s += dk;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t = block_sum_per_sample(s, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) dk_part[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int nblk, int Bp,
+                                                            double* __restrict__ out) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWave + lane;
+  const double a = sum_partials(part, nblk, Bp, b, lds);
+  if (wave == 0 && b < Bp) out[b] = a;
+}
+
+// ---------------------------------------------------------------------------------------
+// (B, n) <-> (n, Bp) through a padded LDS tile
+// ---------------------------------------------------------------------------------------
+constexpr int kT = 64;
+
+__global__ __launch_bounds__(256) void to_node_major_kernel(const double* __restrict__ src, i64 ld,
+                                                             const unsigned char* __restrict__ zero_mask,
+                                                             double* __restrict__ dst, int n, int B, int Bp) {
+  __shared__ double tile[kT][kT + 1];
+  const int i0 = blockIdx.x * kT, b0 = blockIdx.y * kT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int bb = wave; bb < kT; bb += 4) {  // lanes along i: coalesced reads of a sample row
+    const int b = b0 + bb, i = i0 + lane;
+    double v = 0.0;
+    if (b < B && i < n) v = src[(i64)b * ld + i];
+    tile[bb][lane] = v;
+  }
+  __syncthreads();
+  for (int ii = wave; ii < kT; ii += 4) {  // lanes along b: coalesced writes of a node row
+    const int i = i0 + ii, b = b0 + lane;
+    if (i < n && b < Bp) {
+      double v = tile[lane][ii];
+      if (zero_mask && zero_mask[i]) v = 0.0;
+      dst[(i64)i * Bp + b] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void to_sample_major_kernel(const double* __restrict__ src,
+                                                               const double* __restrict__ add, double* __restrict__ dst,
+                                                               i64 ld, int n, int B, int Bp) {
+  __shared__ double tile[kT][kT + 1];
+  const int i0 = blockIdx.x * kT, b0 = blockIdx.y * kT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ii = wave; ii < kT; ii += 4) {
+    const int i = i0 + ii, b = b0 + lane;
+    double v = 0.0;
+    if (i < n && b < Bp) v = src[(i64)i * Bp + b] + (add ? add[i] : 0.0);
+    tile[ii][lane] = v;
+  }
+  __syncthreads();
+  for (int bb = wave; bb < kT; bb += 4) {
+    const int b = b0 + bb, i = i0 + lane;
+    if (b < B && i < n) dst[(i64)b * ld + i] = tile[lane][bb];
+  }
+}
+
+inline int cg_blocks(int n, int Bp) { return (int)node_grid(n, Bp).x; }
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" int diffhe_p1_element_integrals(const double* coords, const int* elems, int dim, int n, int m,
+                                           double* k0, double* m0, void* stream) {
+  if (!coords || !elems || !k0 || !m0 || (dim != 1 && dim != 2) || n < 1 || m < 1) return DIFFHE_E_BADARG;
+  int blocks = (m + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(element_integrals_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, elems, dim, n,
+                     m, k0, m0);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long kappa_se,
+                                        long long kappa_sb, const int* ent_ptr, const int* contrib, const int* cols,
+                                        const unsigned char* is_bc, const double* g, double* vals, double* lift, int n,
+                                        int m, int W, int Bv, void* stream) {
+  if (!local || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
+  if (is_bc && !g) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  hipLaunchKernelGGL(assemble_rows_kernel, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local, kappa,
+                     kappa_se, kappa_sb, ent_ptr, contrib, cols, is_bc, g, vals, lift, n, m, W, Bv);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_assemble_atomic(const double* coords, const int* elems, int dim, const double* kappa,
+                                          long long kappa_se, long long kappa_sb, const int* slot_of, double* vals,
+                                          int n, int m, int W, int Bp, void* stream) {
+  (void)W;
+  if (!coords || !elems || !slot_of || !vals || (dim != 1 && dim != 2) || n < 1 || m < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  int gx = (m + kElemTile - 1) / kElemTile;
+  if (gx > 4096) gx = 4096;
+  dim3 grid(gx, (Bp + 63) / 64);
+  hipLaunchKernelGGL(assemble_atomic_kernel, grid, dim3(256), 0, (hipStream_t)stream, coords, elems, dim, kappa,
+                     kappa_se, kappa_sb, slot_of, vals, n, m, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_apply_dirichlet(const int* cols, const unsigned char* is_bc, const double* g, double* vals,
+                                          double* F, int n, int W, int Bp, void* stream) {
+  if (!cols || !is_bc || !g || !vals || n < 1 || W < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  hipLaunchKernelGGL(apply_dirichlet_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, cols, is_bc,
+                     g, vals, F, n, W, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_spmv_shared(const double* vals, const int* cols, const double* x, const double* sub,
+                                      int sub_B, const unsigned char* is_bc, double* y, int n, int W, int Bp,
+                                      void* stream) {
+  if (!vals || !cols || !x || !y || n < 1 || W < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
+  hipLaunchKernelGGL(spmv_shared_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, vals, cols, x,
+                     sub, sub_B, is_bc, y, n, W, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" long long diffhe_cg_workspace_doubles(int n, int Bp) {
+  const long long nblk = cg_blocks(n, Bp);
+  return 4LL * n * Bp + 3LL * nblk * Bp + 16LL * Bp + 64;
+}
+
+extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, double* x, int n, int W,
+                                   int Bp, int Bv, double tol, int max_iter, int check_every, double* work,
+                                   double* relres, int* iters, int* status_host, void* stream) {
+  if (!vals || !cols || !b || !x || !work || !relres || !iters || !status_host || n < 1 || W < 1 || max_iter < 0)
+    return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
+  if (check_every < 1) check_every = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = diffhe::node_grid(n, Bp);
+  const int nblk = grid.x;
+  const long long NB = (long long)n * Bp;
+  double* r = work;
+  double* z = r + NB;
+  double* p = z + NB;
+  double* Ap = p + NB;
+  double* partA = Ap + NB;
+  double* partB = partA + (long long)nblk * Bp;
+  double* partC = partB + (long long)nblk * Bp;
+  double* sc = partC + (long long)nblk * Bp;
+  CgScalars S;
+  S.rz = sc; S.pAp = sc + Bp; S.alpha = sc + 2 * Bp; S.beta = sc + 3 * Bp; S.bb = sc + 4 * Bp;
+  S.tol2 = sc + 5 * Bp; S.rr = sc + 6 * Bp;
+  S.active = (int*)(sc + 7 * Bp);
+  S.iters = iters;
+  S.n_active = (int*)(sc + 8 * Bp);
+  const dim3 sgrid((Bp + 63) / 64);
+
+  hipLaunchKernelGGL(cg_init_kernel, grid, dim3(256), 0, st, vals, b, x, r, z, p, partA, partB, n, Bp, Bv);
+  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, partA, partB, nblk, Bp, tol, S, relres);
+  int rc = diffhe::check_launch();
+  if (rc) return rc;
+
+  int it = 0, n_active = -1;
+  while (it < max_iter) {
+    hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, vals, cols, p, Ap, partA, n, W, Bp, Bv);
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, partA, (const double*)nullptr, nblk,
+                       Bp, tol, S, relres);
+    hipLaunchKernelGGL(cg_update_kernel, grid, dim3(256), 0, st, vals, p, Ap, S.alpha, x, r, z, partB, partC, n, Bp,
+                       Bv);
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, partB, partC, nblk, Bp, tol, S, relres);
+    hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, S.beta, p, n, Bp);
+    ++it;
+    if (it % check_every == 0 || it == max_iter) {
+      rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+      if (rc) return rc;
+      rc = diffhe::check(hipStreamSynchronize(st));
+      if (rc) return rc;
+      n_active = status_host[2];
+      if (n_active == 0) break;
+    }
+  }
+  hipLaunchKernelGGL(residual_kernel, grid, dim3(256), 0, st, vals, cols, b, x, partA, n, W, Bp, Bv);
+  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_RELRES, partA, (const double*)nullptr, nblk,
+                     Bp, tol, S, relres);
+  rc = diffhe::check_launch();
+  if (rc) return rc;
+  status_host[0] = it;
+  status_host[1] = n_active < 0 ? 0 : n_active;
+  return DIFFHE_OK;
+}
+
+extern "C" int diffhe_grad_kappa_blocks(int m, int Bp) { return (int)diffhe::node_grid(m, Bp).x; }
+
+extern "C" int diffhe_p1_grad_kappa(const int* elems, const double* k0, const double* lam, const double* u,
+                                    const double* g, int npe, int m, int Bp, double* dk_e, double* dk_part,
+                                    double* dk_sum, void* stream) {
+  if (!elems || !k0 || !lam || !u || !dk_part || !dk_sum || (npe != 2 && npe != 3) || m < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  const dim3 grid = diffhe::node_grid(m, Bp);
+  hipLaunchKernelGGL(grad_kappa_kernel, grid, dim3(256), 0, (hipStream_t)stream, elems, k0, lam, u, g, npe, m, Bp,
+                     dk_e, dk_part);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((Bp + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)dk_part, (int)grid.x, Bp, dk_sum);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_to_node_major(const double* src, long long ld, const unsigned char* zero_mask, double* dst, int n,
+                                    int B, int Bp, void* stream) {
+  if (!src || !dst || n < 1 || B < 1 || Bp < B) return DIFFHE_E_BADARG;
+  dim3 grid((n + kT - 1) / kT, (Bp + kT - 1) / kT);
+  hipLaunchKernelGGL(to_node_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, zero_mask, dst, n, B, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_to_sample_major(const double* src, const double* add, double* dst, long long ld, int n, int B,
+                                      int Bp, void* stream) {
+  if (!src || !dst || n < 1 || B < 1 || Bp < B) return DIFFHE_E_BADARG;
+  dim3 grid((n + kT - 1) / kT, (Bp + kT - 1) / kT);
+  hipLaunchKernelGGL(to_sample_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, ld, n, B, Bp);
+  return diffhe::check_launch();
+}

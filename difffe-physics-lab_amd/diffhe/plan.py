@@ -1,0 +1,192 @@
+"""Per-mesh solve plan: the batch-invariant integer metadata the HIP kernels need.
+
+Built once per (mesh, device) with vectorised numpy and cached on the mesh object:
+  * chain detection + Dirichlet-delimited segments for the 1D scan solver;
+  * the ELL pattern shared by the whole batch, the per-entry contribution lists
+    of the deterministic gather assembly, the per-element slot map of the atomic
+    assembly;
+  * element integrals k0 / m0 and the load matrix M (computed ON THE DEVICE by
+    `diffhe_p1_element_integrals` / `diffhe_ell_assemble_rows`).
+
+Nothing here solves anything: it replaces the bookkeeping of reference
+mesh.py:127-129 (`free_nodes`) and the index arithmetic implicit in the dense
+`K[i, j]` writes of solver.py:89-92 / :137-140.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+def padded_batch(B: int) -> int:
+    """Bp: next power of two up to 64, else the next multiple of 64."""
+    if B <= 64:
+        p = 1
+        while p < B:
+            p *= 2
+        return p
+    return ((B + 63) // 64) * 64
+
+
+def _bc_arrays(mesh):
+    n = mesh.n_nodes
+    is_bc = np.zeros(n, dtype=np.uint8)
+    g = np.zeros(n, dtype=np.float64)
+    if mesh.dirichlet_nodes:
+        keys = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64, count=len(mesh.dirichlet_nodes))
+        vals = np.fromiter((float(v) for v in mesh.dirichlet_nodes.values()), dtype=np.float64,
+                           count=len(mesh.dirichlet_nodes))
+        is_bc[keys] = 1
+        g[keys] = vals
+    return is_bc, g
+
+
+def chain_segments(n: int, is_bc: np.ndarray) -> np.ndarray:
+    """(n_seg, 3) int32 rows (first node, last node, flags); flags bit0/bit1 = the
+    first/last node is Dirichlet.  Segments are the maximal runs between Dirichlet nodes."""
+    d = np.nonzero(is_bc)[0]
+    if len(d) == 0:
+        return np.array([[0, n - 1, 0]], dtype=np.int32)
+    segs = []
+    if d[0] > 0:
+        segs.append((0, int(d[0]), 2))
+    for a, b in zip(d[:-1], d[1:]):
+        segs.append((int(a), int(b), 3))
+    if d[-1] < n - 1:
+        segs.append((int(d[-1]), n - 1, 1))
+    if not segs:  # n == 1
+        segs.append((0, n - 1, 3))
+    return np.asarray(segs, dtype=np.int32)
+
+
+def build_ell_pattern(elements: np.ndarray, n: int):
+    """ELL pattern + gather lists from the connectivity.
+
+    Returns dict(W, cols (W,n) i32, ent_ptr (W*n+1) i32, contrib i32, slot_of (npe*npe, m) i32).
+    Entry (row i, slot k) is stored at k*n + i; slot 0 is the diagonal; unused slots
+    point at the row itself and carry no contribution.
+    """
+    m, npe = elements.shape
+    nloc = npe * npe
+    e_idx = np.repeat(np.arange(m, dtype=np.int64), nloc)
+    pq = np.tile(np.arange(nloc, dtype=np.int64), m)
+    rows = elements[e_idx, pq // npe].astype(np.int64)
+    cols = elements[e_idx, pq % npe].astype(np.int64)
+    # every row owns a diagonal entry even if no element touches the node
+    rows_all = np.concatenate([np.arange(n, dtype=np.int64), rows])
+    cols_all = np.concatenate([np.arange(n, dtype=np.int64), cols])
+    # sort key: row, then (diagonal first), then column
+    offdiag = (rows_all != cols_all).astype(np.int64)
+    key = (rows_all * 2 + offdiag) * n + cols_all
+    order = np.argsort(key, kind="stable")
+    key_s = key[order]
+    new_entry = np.ones(len(key_s), dtype=bool)
+    new_entry[1:] = key_s[1:] != key_s[:-1]
+    entry_id = np.cumsum(new_entry) - 1                     # entry index in (row, slot) order
+    ent_rows = rows_all[order][new_entry]
+    ent_cols = cols_all[order][new_entry]
+    row_start = np.searchsorted(ent_rows, np.arange(n))
+    slot = np.arange(len(ent_rows)) - row_start[ent_rows]   # slot within the row
+    W = int(slot.max()) + 1
+    ell_cols = np.tile(np.arange(n, dtype=np.int32), W)
+    ell_index = slot * n + ent_rows                          # k*n + i
+    ell_cols[ell_index] = ent_cols.astype(np.int32)
+    # contributions (drop the synthetic diagonals, which sit in the first n inputs)
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.arange(len(order))
+    contrib_entry = ell_index[entry_id[inv[n:]]]             # ELL index of each (e, pq)
+    code = (e_idx * 16 + pq).astype(np.int64)
+    corder = np.argsort(contrib_entry, kind="stable")        # fixed order: deterministic sums
+    contrib = code[corder].astype(np.int32)
+    counts = np.bincount(contrib_entry, minlength=W * n)
+    ent_ptr = np.zeros(W * n + 1, dtype=np.int64)
+    np.cumsum(counts, out=ent_ptr[1:])
+    slot_of = (contrib_entry // n).reshape(m, nloc).T.copy().astype(np.int32)
+    if ent_ptr[-1] >= 2 ** 31 or m >= 2 ** 27:
+        raise ValueError("mesh too large for int32 gather lists")
+    return dict(W=W, cols=ell_cols.reshape(W, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib,
+                slot_of=slot_of)
+
+
+class SolvePlan:
+    """Device-resident metadata of one mesh (see module docstring)."""
+
+    def __init__(self, mesh, device: torch.device):
+        L = _hip.lib()
+        self.device = device
+        self.dim = mesh.dim
+        self.n = mesh.n_nodes
+        self.m = mesh.n_elements
+        self.npe = self.dim + 1
+        if self.dim not in (1, 2):
+            raise NotImplementedError("Only 1D and 2D supported")  # reference solver.py:67
+        nodes = mesh.nodes.detach().to("cpu", torch.float64).numpy()
+        elements = mesh.elements.detach().to("cpu", torch.int64).numpy()
+        if elements.shape[1] != self.npe:
+            raise ValueError(f"expected {self.npe} nodes per element, got {elements.shape[1]}")
+        is_bc, g = _bc_arrays(mesh)
+        self.n_bc = int(is_bc.sum())
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        self.is_bc = dev(is_bc)
+        self.g = dev(g)
+        self.coords = dev(nodes.T)                                   # (dim, n) SoA
+        self.elems = dev(elements.T.astype(np.int32))                # (npe, m) SoA
+        self.pinned_status = torch.zeros(4, dtype=torch.int32).pin_memory()
+
+        # --- 1D chain fast path ---------------------------------------------------------
+        self.is_chain = bool(self.dim == 1 and self.n == self.m + 1
+                             and np.array_equal(elements[:, 0], np.arange(self.m))
+                             and np.array_equal(elements[:, 1], np.arange(1, self.m + 1)))
+        if self.is_chain:
+            seg = chain_segments(self.n, is_bc)
+            self.n_seg = len(seg)
+            self.seg = dev(seg)
+            self.x = self.coords[0].contiguous()
+            return
+
+        # --- general ELL path -----------------------------------------------------------
+        pat = build_ell_pattern(elements, self.n)
+        self.W = pat["W"]
+        self.cols = dev(pat["cols"])
+        self.ent_ptr = dev(pat["ent_ptr"])
+        self.contrib = dev(pat["contrib"])
+        self.slot_of = dev(pat["slot_of"])
+        stream = _stream(device)
+        nloc = self.npe * self.npe
+        self.k0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
+        self.m0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
+        _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), self.dim, self.n,
+                                                 self.m, _hip.ptr(self.k0), _hip.ptr(self.m0), stream),
+                   "diffhe_p1_element_integrals")
+        # load matrix M (batch-shared ELL values): F = M f, df = M^T lambda
+        self.Mvals = torch.empty((self.W, self.n), dtype=torch.float64, device=device)
+        _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self.m0), None, 0, 0, _hip.ptr(self.ent_ptr),
+                                              _hip.ptr(self.contrib), _hip.ptr(self.cols), None, None,
+                                              _hip.ptr(self.Mvals), None, self.n, self.m, self.W, 1, stream),
+                   "diffhe_ell_assemble_rows(M)")
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _fingerprint(mesh):
+    bc = mesh.dirichlet_nodes
+    return (id(mesh.nodes), mesh.nodes._version, id(mesh.elements), mesh.elements._version, len(bc),
+            hash(tuple(bc.items())) if len(bc) <= 1 << 16 else (hash(tuple(bc.keys())), hash(tuple(bc.values()))))
+
+
+def get_plan(mesh, device: torch.device) -> SolvePlan:
+    """Cached plan for (mesh, device); rebuilt when nodes/elements/BCs change."""
+    cache = mesh.__dict__.setdefault("_diffhe_plans", {})
+    key = (str(device), _fingerprint(mesh))
+    plan: Optional[SolvePlan] = cache.get(key)
+    if plan is None:
+        cache.clear()
+        plan = SolvePlan(mesh, device)
+        cache[key] = plan
+    return plan

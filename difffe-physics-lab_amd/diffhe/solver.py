@@ -1,0 +1,336 @@
+"""Differentiable P1-FEM solve of -div(kappa grad u) = f with Dirichlet data, on MI355X.
+
+Mirror of the reference operator `DifferentiableFESolver` (reference
+diffhe/solver.py:21-183): same constructor, `.kappa`, `forward(f) -> u`, same
+unbatched semantics (float64 output, Dirichlet values exact, gradients to kappa
+and f).  The work is done by hand-written HIP kernels behind the C ABI of
+include/diffhe_hip.h; the adjoint is explicit, not autograd
+replay.  There is no CPU fallback: without the HIP library or a GPU, `forward`
+raises.
+
+Extensions over the reference (which has no batch dimension, solver.py:54):
+  f      (n,) | (n,1) | (B,n)
+  kappa  python scalar | 0-dim / 1-element tensor | (m,) per element |
+         (B,1) or (B,) per sample | (B,m) per sample and element
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .mesh import FEMesh
+from .plan import SolvePlan, get_plan, padded_batch, _stream
+
+# kappa layouts
+K_SCALAR, K_SAMPLE, K_ELEM, K_SAMPLE_ELEM = 0, 1, 2, 3
+
+
+@dataclass
+class SolveInfo:
+    """Diagnostics of the last solve (the reference silently returns garbage on
+    failure; we surface it instead)."""
+    path: str = ""
+    iterations: int = 0
+    not_converged: int = 0
+    max_relres: float = 0.0
+    adj_iterations: int = 0
+    adj_max_relres: float = 0.0
+
+
+def _resolve_device(device) -> torch.device:
+    if device is not None:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("diffhe runs on a ROCm GPU only (no CPU fallback)")
+        return device
+    if not torch.cuda.is_available():
+        raise RuntimeError("diffhe: no ROCm GPU visible -- the HIP solve path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _kappa_mode(kappa: torch.Tensor, m: int, B: Optional[int]):
+    """Classify kappa -> (mode, B implied or None)."""
+    if kappa.numel() == 1:
+        return K_SCALAR, None
+    if kappa.dim() == 1:
+        if kappa.shape[0] == m and (B is None or B == 1 or B != m):
+            return K_ELEM, None
+        return K_SAMPLE, kappa.shape[0]
+    if kappa.dim() == 2:
+        if kappa.shape[1] == 1:
+            return K_SAMPLE, kappa.shape[0]
+        if kappa.shape[1] == m:
+            return K_SAMPLE_ELEM, kappa.shape[0]
+    raise ValueError(f"kappa shape {tuple(kappa.shape)} not understood for a mesh with {m} elements")
+
+
+class _Engine:
+    """Thin, stateless driver of the C ABI for one plan and one batch geometry."""
+
+    def __init__(self, plan: SolvePlan, tol: float, max_iter: int, check_every: int, assembly: str):
+        self.p = plan
+        self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
+        self.L = _hip.lib()
+
+    # -- layout helpers -----------------------------------------------------------------
+    def to_node_major(self, src, B, Bp, n, zero_mask=None):
+        """(B, n) rows -- or one (n,) vector broadcast to all B samples -- to (n, Bp)."""
+        p = self.p
+        dst = torch.empty((n, Bp), dtype=torch.float64, device=p.device)
+        ld = 0 if src.dim() == 1 else src.stride(0)
+        _hip.check(self.L.diffhe_to_node_major(_hip.ptr(src), ld, _hip.ptr(zero_mask), _hip.ptr(dst), n, B, Bp,
+                                               _stream(p.device)), "diffhe_to_node_major")
+        return dst
+
+    def to_sample_major(self, src, B, Bp, n, add=None):
+        p = self.p
+        dst = torch.empty((B, n), dtype=torch.float64, device=p.device)
+        _hip.check(self.L.diffhe_to_sample_major(_hip.ptr(src), _hip.ptr(add), _hip.ptr(dst), n, n, B, Bp,
+                                                 _stream(p.device)), "diffhe_to_sample_major")
+        return dst
+
+    # -- general path ---------------------------------------------------------------------
+    def kappa_device(self, kappa, mode, B, Bp):
+        """-> (tensor, stride_e, stride_b, Bv) in the layout the kernels index."""
+        p = self.p
+        k = kappa.detach().to(p.device, torch.float64)
+        if mode == K_SCALAR:
+            return k.reshape(1).contiguous(), 0, 0, 1
+        if mode == K_ELEM:
+            return k.reshape(p.m).contiguous(), 1, 0, 1
+        if mode == K_SAMPLE:
+            kp = torch.ones(Bp, dtype=torch.float64, device=p.device)
+            kp[:B] = k.reshape(B)
+            return kp, 0, 1, Bp
+        kp = self.to_node_major(k.reshape(B, p.m).contiguous(), B, Bp, p.m)
+        if Bp > B:
+            kp[:, B:] = 1.0
+        return kp, Bp, 1, Bp
+
+    def assemble(self, kdev, kse, ksb, Bv):
+        p, L = self.p, self.L
+        st = _stream(p.device)
+        vals = torch.empty((p.W, p.n, Bv), dtype=torch.float64, device=p.device)
+        lift = torch.empty((p.n, Bv), dtype=torch.float64, device=p.device)
+        if self.assembly == "atomic" and Bv > 1:
+            vals.zero_()
+            _hip.check(L.diffhe_ell_assemble_atomic(_hip.ptr(p.coords), _hip.ptr(p.elems), p.dim, _hip.ptr(kdev), kse,
+                                                    ksb, _hip.ptr(p.slot_of), _hip.ptr(vals), p.n, p.m, p.W, Bv, st),
+                       "diffhe_ell_assemble_atomic")
+            lift.zero_()  # apply_dirichlet returns F - lift: feed F = 0, negate
+            _hip.check(L.diffhe_ell_apply_dirichlet(_hip.ptr(p.cols), _hip.ptr(p.is_bc), _hip.ptr(p.g),
+                                                    _hip.ptr(vals), _hip.ptr(lift), p.n, p.W, Bv, st),
+                       "diffhe_ell_apply_dirichlet")
+            lift.neg_()
+        else:
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(p.k0), _hip.ptr(kdev), kse, ksb, _hip.ptr(p.ent_ptr),
+                                                  _hip.ptr(p.contrib), _hip.ptr(p.cols), _hip.ptr(p.is_bc),
+                                                  _hip.ptr(p.g), _hip.ptr(vals), _hip.ptr(lift), p.n, p.m, p.W, Bv,
+                                                  st), "diffhe_ell_assemble_rows")
+        return vals, lift
+
+    def load_vector(self, f_nm, lift, Bv, Bp):
+        p = self.p
+        F = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(f_nm), _hip.ptr(lift),
+                                                 Bv, _hip.ptr(p.is_bc), _hip.ptr(F), p.n, p.W, Bp,
+                                                 _stream(p.device)), "diffhe_ell_spmv_shared")
+        return F
+
+    def apply_M(self, x_nm, Bp):
+        p = self.p
+        y = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(x_nm), None, 1, None,
+                                                 _hip.ptr(y), p.n, p.W, Bp, _stream(p.device)),
+                   "diffhe_ell_spmv_shared")
+        return y
+
+    def cg(self, vals, rhs, Bp, Bv):
+        p, L = self.p, self.L
+        x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        work = torch.empty(L.diffhe_cg_workspace_doubles(p.n, Bp), dtype=torch.float64, device=p.device)
+        relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        _hip.check(L.diffhe_ell_cg_solve(_hip.ptr(vals), _hip.ptr(p.cols), _hip.ptr(rhs), _hip.ptr(x), p.n, p.W, Bp,
+                                         Bv, self.tol, self.max_iter, self.check_every, _hip.ptr(work),
+                                         _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
+                                         _stream(p.device)), "diffhe_ell_cg_solve")
+        st = p.pinned_status
+        return x, int(st[0]), int(st[1]), relres
+
+    def grad_kappa(self, lam, x, Bp, want_elem):
+        p, L = self.p, self.L
+        nblk = L.diffhe_grad_kappa_blocks(p.m, Bp)
+        dk_e = torch.empty((p.m, Bp), dtype=torch.float64, device=p.device) if want_elem else None
+        part = torch.empty((nblk, Bp), dtype=torch.float64, device=p.device)
+        dk_sum = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        _hip.check(L.diffhe_p1_grad_kappa(_hip.ptr(p.elems), _hip.ptr(p.k0), _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
+                                          p.npe, p.m, Bp, _hip.ptr(dk_e), _hip.ptr(part), _hip.ptr(dk_sum),
+                                          _stream(p.device)), "diffhe_p1_grad_kappa")
+        return dk_e, dk_sum
+
+
+class _FESolve(torch.autograd.Function):
+    """u = K(kappa)^{-1} F(f) with Dirichlet elimination; explicit adjoint."""
+
+    @staticmethod
+    def forward(ctx, kappa, f, solver):
+        plan: SolvePlan = solver._plan()
+        eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
+        out_device = f.device
+        batched = f.dim() == 2
+        m, n = plan.m, plan.n
+        B_f = f.shape[0] if batched else None
+        mode, B_k = _kappa_mode(kappa, m, B_f)
+        B = B_f if B_f is not None else (B_k if B_k is not None else 1)
+        if B_k is not None and B_k != B:
+            raise ValueError(f"kappa batch {B_k} does not match f batch {B}")
+        f_dev = f.detach().to(plan.device, torch.float64).contiguous()
+        info = SolveInfo()
+        ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
+        ctx.mode, ctx.B, ctx.batched_f, ctx.out_device = mode, B, batched, out_device
+        ctx.kappa_shape, ctx.kappa_device = kappa.shape, kappa.device
+
+        if plan.is_chain:
+            info.path = "chain1d-scan"
+            L = eng.L
+            kdev = kappa.detach().to(plan.device, torch.float64).contiguous()
+            ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
+            u = torch.empty((B, n), dtype=torch.float64, device=plan.device)
+            stage = None
+            if 16 * (n - 1) > 160 * 1024 - 2048:
+                stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+            _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
+                                              n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
+                                              _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
+                       "diffhe_chain1d_solve")
+            ctx.saved = (kdev, ksb, kse, u)
+        else:
+            info.path = "ell-pcg"
+            Bp = padded_batch(B)
+            kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
+            vals, lift = eng.assemble(kdev, kse, ksb, Bv)
+            f_nm = eng.to_node_major(f_dev, B, Bp, n)
+            rhs = eng.load_vector(f_nm, lift, Bv, Bp)
+            x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+            info.iterations, info.not_converged = its, bad
+            info.max_relres = float(relres[:B].max())
+            u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+            ctx.saved = (vals, x, Bp, Bv)
+        solver.last_info = info
+        out = u if batched or B > 1 else u[0]
+        return out.to(out_device)
+
+    @staticmethod
+    def backward(ctx, gbar):
+        plan, eng, mode, B = ctx.plan, ctx.eng, ctx.mode, ctx.B
+        m, n = plan.m, plan.n
+        need_k, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
+        info = ctx.solver.last_info
+        if plan.is_chain:
+            kdev, ksb, kse, u = ctx.saved
+            L = eng.L
+            df = torch.empty((B, n), dtype=torch.float64, device=plan.device)
+            want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
+            dk_e = torch.empty((B, m), dtype=torch.float64, device=plan.device) if want_e else None
+            part = torch.empty((B, plan.n_seg), dtype=torch.float64, device=plan.device)
+            stage = None
+            if 16 * (n - 1) > 160 * 1024 - 2048:
+                stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+            _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(g_dev), n,
+                                                _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(df), n,
+                                                _hip.ptr(dk_e), m, _hip.ptr(part), n, B, _hip.ptr(stage),
+                                                _stream(plan.device)), "diffhe_chain1d_adjoint")
+            dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
+            dk_elem = dk_e
+        else:
+            vals, x, Bp, Bv = ctx.saved
+            rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
+            lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+            info.adj_iterations = its
+            info.adj_max_relres = float(relres[:B].max())
+            info.not_converged += bad
+            want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
+            dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e) if need_k else (None, None)
+            dk_sample = dk_sum[:B] if need_k else None
+            dk_elem = None
+            if need_k and want_e:
+                dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
+            df = eng.to_sample_major(eng.apply_M(lam, Bp), B, Bp, n) if need_f else None
+
+        grad_k = None
+        if need_k:
+            if mode == K_SCALAR:
+                grad_k = dk_sample.sum().reshape(ctx.kappa_shape)
+            elif mode == K_SAMPLE:
+                grad_k = dk_sample.reshape(ctx.kappa_shape)
+            elif mode == K_ELEM:
+                grad_k = dk_elem.sum(dim=0).reshape(ctx.kappa_shape)
+            else:
+                grad_k = dk_elem.reshape(ctx.kappa_shape)
+            grad_k = grad_k.to(ctx.kappa_device)
+        grad_f = None
+        if need_f:
+            grad_f = df if ctx.batched_f else df.sum(dim=0)
+            grad_f = grad_f.to(ctx.out_device)
+        return grad_k, grad_f, None
+
+
+class DifferentiableFESolver(nn.Module):
+    """Assemble and solve the P1 system of a mesh for a forcing (reference solver.py:21-43).
+
+    Parameters
+    ----------
+    mesh : FEMesh
+    kappa : float or torch.Tensor -- diffusion coefficient (see module docstring).
+    device, tol, max_iter, check_every, assembly : HIP-path knobs (ours; the
+        reference has none).  `assembly` is "gather" (deterministic) or "atomic".
+    """
+
+    def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: float = 1e-12,
+                 max_iter: int = 20000, check_every: int = 25, assembly: str = "gather"):
+        super().__init__()
+        self.mesh = mesh
+        if isinstance(kappa, (int, float)):
+            self._kappa = torch.tensor(kappa, dtype=torch.float64)        # reference solver.py:36-37
+        else:
+            self._kappa = kappa.to(dtype=torch.float64)                  # reference solver.py:38-39
+        if assembly not in ("gather", "atomic"):
+            raise ValueError(f"Unknown assembly: {assembly!r}")
+        self._device = device
+        self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
+        self.last_info = SolveInfo()
+
+    @property
+    def kappa(self) -> torch.Tensor:
+        return self._kappa
+
+    def _plan(self) -> SolvePlan:
+        return get_plan(self.mesh, _resolve_device(self._device))
+
+    def forward(self, f: torch.Tensor) -> torch.Tensor:
+        """Solve for nodal u.  f: (n,), (n,1) or (B,n); returns float64 (n,) or (B,n)
+        on f's device (reference solver.py:49-67 returns CPU float64)."""
+        if self.mesh.dim not in (1, 2):
+            raise NotImplementedError("Only 1D and 2D supported")       # reference solver.py:67
+        n = self.mesh.n_nodes
+        f64 = f.to(torch.float64)
+        if f64.dim() == 2 and f64.shape == (n, 1):
+            f64 = f64.reshape(n)                                          # (n,1) works in the reference too
+        elif f64.dim() == 2 and f64.shape[1] != n:
+            raise ValueError(f"f must be (n,) or (B,n) with n={n}, got {tuple(f.shape)}")
+        elif f64.dim() == 1 and f64.shape[0] != n:
+            raise ValueError(f"f must have {n} nodal values, got {f64.shape[0]}")
+        return _FESolve.apply(self._kappa, f64, self)
+
+    # reference-private names kept as aliases; both run the HIP path
+    def _solve_1d(self, f: torch.Tensor) -> torch.Tensor:
+        return self.forward(f)
+
+    def _solve_2d(self, f: torch.Tensor) -> torch.Tensor:
+        return self.forward(f)

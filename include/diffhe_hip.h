@@ -1,0 +1,163 @@
+/*
+ * diffhe_hip.h -- C ABI of libdiffhe_hip.so: the MI355X (gfx950) differentiable
+ * P1-FEM solve path behind diffhe.DifferentiableFESolver.
+ *
+ * The reference (danieleschmidt/DiffFE-Physics-Lab) has no FFI of its own: its hot
+ * path is three Python methods (diffhe/solver.py:73-98 `_solve_1d`, :104-147
+ * `_solve_2d`, :153-183 `_apply_bc_and_solve`) whose adjoint is whatever autograd
+ * replays.  Each entry point below replaces a slice of those methods; the slice is
+ * cited per function.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - values are fp64, indices int32, sizes `int`/`long long`;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered;
+ *   - functions return 0 (DIFFHE_OK) or a negative DIFFHE_E_* code, never throw,
+ *     never allocate: workspaces are caller-owned;
+ *   - 1D chain path: sample-major (B, n) arrays with an explicit row stride;
+ *   - 2D/general path: node-major, batch-innermost arrays `(n, Bp)`:
+ *     element (i, b) lives at `i * Bp + b`, Bp = padded batch (power of two <= 64
+ *     or a multiple of 64).  The mesh pattern is shared by the whole batch.
+ */
+#ifndef DIFFHE_HIP_H
+#define DIFFHE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIFFHE_ABI_VERSION 1
+
+#define DIFFHE_OK 0
+#define DIFFHE_E_BADARG (-1)
+#define DIFFHE_E_LAUNCH (-2)   /* a HIP launch/runtime call failed */
+#define DIFFHE_E_TOOBIG (-3)   /* problem exceeds what this entry point supports */
+#define DIFFHE_E_BATCHPAD (-4) /* Bp is not a power of two <= 64 or a multiple of 64 */
+
+int diffhe_abi_version(void);
+const char* diffhe_status_string(int status);
+/* hipGetLastError()-style text of the last DIFFHE_E_LAUNCH on this thread. */
+const char* diffhe_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------
+ * 1D chain path (elements[e] = (e, e+1)).  Fused assemble + solve; K is never
+ * materialised.  The P1 stiffness of a chain is a weighted path-graph Laplacian:
+ * its inverse is two prefix sums (flux scan, then potential scan), evaluated per
+ * Dirichlet-delimited segment by one workgroup per (segment, sample).
+ *
+ * Replaces solver.py:73-98 (element integrals h_e, k_e = kappa/h_e, lumped load
+ * h_e/2 f_i) + solver.py:153-183 (elimination, solve, scatter-back).
+ *
+ *   x        (n)            node coordinates
+ *   kappa    kappa[b*kappa_sb + e*kappa_se]   (strides 0 broadcast)
+ *   rhs      rhs[b*rhs_sb + i]  nodal forcing f (rhs_sb = 0 shares one f)
+ *   seg      (n_seg, 3) int32: first node, last node, flags
+ *            (bit0: first node is Dirichlet, bit1: last node is Dirichlet)
+ *   g        (n) Dirichlet values (0 at free nodes)
+ *   u        (B, n) out, row stride ldu
+ *   stage    optional global staging buffer, (B * n_seg) * 2 * max_seg_len doubles,
+ *            used only when a segment does not fit LDS (may be NULL otherwise)
+ * ---------------------------------------------------------------------------- */
+int diffhe_chain1d_solve(const double* x, const double* kappa, long long kappa_sb, long long kappa_se,
+                         const double* rhs, long long rhs_sb, const int* seg, int n_seg, const double* g,
+                         double* u, long long ldu, int n, int B, double* stage, void* stream);
+
+/* Adjoint of the above (reverse of solver.py:89-96,169-181):
+ *   lambda = K_free^{-1} gbar_free (lambda = 0 on Dirichlet nodes);
+ *   df[b,i]      = lambda_i * sum_{e ni i} h_e/2
+ *   dkappa_e[b,e] = -(lambda_{e+1}-lambda_e)(u_{e+1}-u_e)/h_e        (optional, may be NULL)
+ *   dkappa_part[b*n_seg + s] = sum over the elements of segment s of dkappa_e
+ */
+int diffhe_chain1d_adjoint(const double* x, const double* kappa, long long kappa_sb, long long kappa_se,
+                           const double* gbar, long long gbar_sb, const double* u, long long ldu,
+                           const int* seg, int n_seg, double* df, long long lddf, double* dkappa_e,
+                           long long lddk, double* dkappa_part, int n, int B, double* stage, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * General P1 path (any 1D/2D mesh): per-element integrals, deterministic gather
+ * assembly into a batch-shared ELL pattern, Dirichlet elimination, batched PCG.
+ * ---------------------------------------------------------------------------- */
+
+/* Element integrals, batch-invariant (solver.py:84-88 1D; solver.py:119-139 2D).
+ *   coords (dim, n) SoA; elems (npe, m) SoA int32, npe = dim + 1
+ *   k0 (npe*npe, m): unit-kappa local stiffness, entry p*npe+q
+ *   m0 (npe*npe, m): local load map (1D: diag h/2; 2D: area/9 everywhere)
+ *   degenerate triangles (area < 1e-15, solver.py:120-121) get zeros. */
+int diffhe_p1_element_integrals(const double* coords, const int* elems, int dim, int n, int m,
+                                double* k0, double* m0, void* stream);
+
+/* Deterministic row-gather assembly with fused Dirichlet elimination.
+ * Replaces the scatter-add of solver.py:89-92 / :137-140 and the elimination of
+ * solver.py:165-171.
+ *   local     (npe*npe, m) local matrices (k0 or m0)
+ *   kappa     kappa[e*kappa_se + b*kappa_sb] or NULL for kappa == 1
+ *   ent_ptr   (n*W + 1) CSR over ELL entries (row i, slot k) -> contributions
+ *   contrib   packed (e * 16 + p*npe+q)
+ *   cols      (W, n) ELL column ids, slot 0 = diagonal, padding = own row
+ *   is_bc     (n) bytes or NULL (no elimination: raw K);  g (n) Dirichlet values
+ *   vals      out (W, n, Bv); Bv = padded batch, or 1 when kappa is batch-shared
+ *   lift      out (n, Bv) or NULL: lift_i = sum_{j in bc} K_ij g_j (0 on Dirichlet rows);
+ *             Dirichlet rows become identity rows, couplings to Dirichlet columns 0.
+ */
+int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long kappa_se, long long kappa_sb,
+                             const int* ent_ptr, const int* contrib, const int* cols, const unsigned char* is_bc,
+                             const double* g, double* vals, double* lift, int n, int m, int W, int Bv,
+                             void* stream);
+
+/* Element-parallel assembly with fp64 global atomics (the literal scatter-add of
+ * solver.py:89-92 / :137-140): element integrals are computed from coords and
+ * staged in LDS, then scattered for all Bp samples.  `vals` must be zeroed by the
+ * caller; `slot_of` (npe*npe, m) gives the ELL slot of entry (p,q) of element e.
+ * No Dirichlet handling (use diffhe_ell_apply_dirichlet). */
+int diffhe_ell_assemble_atomic(const double* coords, const int* elems, int dim, const double* kappa,
+                               long long kappa_se, long long kappa_sb, const int* slot_of, double* vals, int n,
+                               int m, int W, int Bp, void* stream);
+
+/* Dirichlet elimination on an assembled ELL matrix (solver.py:165-171). */
+int diffhe_ell_apply_dirichlet(const int* cols, const unsigned char* is_bc, const double* g, double* vals,
+                               double* F, int n, int W, int Bp, void* stream);
+
+/* y = is_bc ? 0 : (M x - sub) for a batch-shared ELL matrix (values (W, n)): the
+ * load vector F = M f (solver.py:95-96 / :143-145) minus the Dirichlet lift
+ * (solver.py:166-169), and the adjoint df = M^T lambda (M symmetric; sub = is_bc = NULL).
+ *   sub (n, sub_B) with sub_B == Bp or 1 (batch-shared), or NULL */
+int diffhe_ell_spmv_shared(const double* vals, const int* cols, const double* x, const double* sub, int sub_B,
+                           const unsigned char* is_bc, double* y, int n, int W, int Bp, void* stream);
+
+/* Batched Jacobi-preconditioned CG on (W, n, Bv) ELL values, all samples at once.
+ * Replaces torch.linalg.solve (solver.py:174) and, for the adjoint, the solve in
+ * its autograd backward.  x is the output (initial guess 0).
+ *   vals     (W, n, Bv), Bv = Bp or 1 (matrix shared by the batch)
+ *   work     diffhe_cg_workspace_doubles(n, Bp) doubles
+ *   status_host  pinned host int[4]: [0] iterations run, [1] samples not converged, [2] scratch
+ *   relres   (Bp) out: true relative residual |b - A x| / |b| per sample
+ *   iters    (Bp) out: iterations each sample was active
+ */
+long long diffhe_cg_workspace_doubles(int n, int Bp);
+int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, double* x, int n, int W, int Bp,
+                        int Bv, double tol, int max_iter, int check_every, double* work, double* relres,
+                        int* iters, int* status_host, void* stream);
+
+/* dL/dkappa contraction (reverse of solver.py:89-92 / :137-140, Appendix A step 2):
+ *   dk[e,b] = - sum_{p,q} lambda[elem_p,b] * k0[p*npe+q, e] * (u[elem_q,b] + g[elem_q])
+ *   (u is the eliminated-system solution, 0 on Dirichlet nodes; g (n) adds the Dirichlet
+ *   values back, may be NULL)
+ *   dk_e (m, Bp) optional; dk_part (nblk, Bp) block partial sums over elements,
+ *   dk_sum (Bp) their deterministic total. nblk = diffhe_grad_kappa_blocks(m, Bp). */
+int diffhe_grad_kappa_blocks(int m, int Bp);
+int diffhe_p1_grad_kappa(const int* elems, const double* k0, const double* lam, const double* u, const double* g,
+                         int npe, int m, int Bp, double* dk_e, double* dk_part, double* dk_sum, void* stream);
+
+/* Layout changes between the API's (B, n) and the solver's (n, Bp).
+ * to_node_major: dst[i*Bp + b] = src[b*ld + i] (b < B), 0 for padding samples and
+ *   where zero_mask[i] != 0 (zero_mask may be NULL; src row stride ld = 0 broadcasts).
+ * to_sample_major: dst[b*ld + i] = src[i*Bp + b] + add[i] (add may be NULL). */
+int diffhe_to_node_major(const double* src, long long ld, const unsigned char* zero_mask, double* dst, int n, int B,
+                         int Bp, void* stream);
+int diffhe_to_sample_major(const double* src, const double* add, double* dst, long long ld, int n, int B, int Bp,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFHE_HIP_H */

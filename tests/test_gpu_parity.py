@@ -1,0 +1,316 @@
+"""GPU parity tests: the HIP path (through the Python boundary and the C ABI) against
+the golden vectors produced by the reference and against the CPU oracle on the same
+seeded inputs.  Stated tolerance: 1e-10 relative (max-norm) on nodal u, dL/dkappa and
+dL/df (BASELINE.json north_star)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from diffhe import FEMesh, DifferentiableFESolver, PhysicsLoss
+from diffhe import _hip
+from diffhe.plan import get_plan
+from oracle import p1_oracle as orc
+from _util import golden, golden_names, rel_err, loss_grad, RTOL_U, RTOL_GRAD
+
+pytestmark = pytest.mark.gpu
+T64 = torch.float64
+
+
+def mesh_from(g):
+    bc = {int(k): float(v) for k, v in zip(g["bc_nodes"], g["bc_vals"])}
+    return FEMesh(nodes=torch.from_numpy(g["nodes"]), elements=torch.from_numpy(g["elements"]), dirichlet_nodes=bc)
+
+
+def arrays(mesh):
+    bn = np.array(list(mesh.dirichlet_nodes.keys()), dtype=np.int64)
+    bv = np.array(list(mesh.dirichlet_nodes.values()), dtype=np.float64)
+    return mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv
+
+
+def torch_loss(kind, u, data=None):
+    if kind == "sum":
+        return u.sum()
+    if kind == "sumsq":
+        return (u ** 2).sum()
+    return ((u - torch.from_numpy(data)) ** 2).mean()
+
+
+def test_extension_is_loaded():
+    assert _hip.lib().diffhe_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("name", ["g1_config1"] + golden_names("g2_1d_fwd_") + ["g4_2d_fwd_32"])
+def test_forward_golden(name):
+    g = golden(name)
+    solver = DifferentiableFESolver(mesh_from(g), float(g["kappa"]))
+    u = solver(torch.from_numpy(g["f"]))
+    assert u.dtype == T64 and u.shape == (len(g["f"]),) and u.device.type == "cpu"
+    assert rel_err(u.numpy(), g["u"]) < RTOL_U, solver.last_info
+    for node, val in zip(g["bc_nodes"], g["bc_vals"]):       # Dirichlet values exact
+        assert abs(float(u[node]) - val) < 1e-12
+    if name == "g1_config1":
+        assert np.max(np.abs(u.numpy() - g["exact"])) < 1e-12
+
+
+@pytest.mark.parametrize("assembly", ["gather", "atomic"])
+@pytest.mark.parametrize("name", golden_names("g3_1d_grad_") + golden_names("g4_2d_0"))
+def test_gradients_golden(name, assembly):
+    g = golden(name)
+    kind = str(g["loss_kind"])
+    kappa = torch.tensor(float(g["kappa"]), dtype=T64, requires_grad=True)
+    f = torch.from_numpy(g["f"]).clone().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh_from(g), kappa, assembly=assembly)
+    u = solver(f)
+    loss = torch_loss(kind, u, g.get("data"))
+    loss.backward()
+    assert rel_err(u.detach().numpy(), g["u"]) < RTOL_U
+    assert abs(float(loss) - float(g["loss"])) <= 1e-10 * abs(float(g["loss"]))
+    assert abs(float(kappa.grad) - float(g["dkappa"])) <= RTOL_GRAD * abs(float(g["dkappa"])), solver.last_info
+    assert rel_err(f.grad.numpy(), g["df"]) < RTOL_GRAD
+
+
+@pytest.mark.parametrize("name", golden_names("g5_asm_"))
+def test_assembled_system_golden(name):
+    """K and F before BCs (reference solver.py:82-96 / :112-145), straight from the C ABI."""
+    g = golden(name)
+    mesh = mesh_from(g)
+    if mesh.dim == 1:   # force the general path: a chain mesh never materialises K
+        perm = np.arange(mesh.n_nodes)[::-1].copy()
+    else:
+        perm = np.arange(mesh.n_nodes)
+    inv = np.argsort(perm)
+    mesh2 = FEMesh(nodes=torch.from_numpy(g["nodes"][inv]), elements=torch.from_numpy(perm[g["elements"]]),
+                   dirichlet_nodes={})
+    dev = torch.device("cuda")
+    plan = get_plan(mesh2, dev)
+    assert not plan.is_chain
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n, m, W = plan.n, plan.m, plan.W
+    kap = torch.full((1,), float(g["kappa"]), dtype=T64, device=dev)
+    for mode in ("gather", "atomic"):
+        Bv = 1 if mode == "gather" else 2
+        vals = torch.zeros((W, n, Bv), dtype=T64, device=dev)
+        if mode == "gather":
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(plan.k0), _hip.ptr(kap), 0, 0, _hip.ptr(plan.ent_ptr),
+                                                  _hip.ptr(plan.contrib), _hip.ptr(plan.cols), None, None,
+                                                  _hip.ptr(vals), None, n, m, W, Bv, st), "rows")
+        else:
+            _hip.check(L.diffhe_ell_assemble_atomic(_hip.ptr(plan.coords), _hip.ptr(plan.elems), plan.dim,
+                                                    _hip.ptr(kap), 0, 0, _hip.ptr(plan.slot_of), _hip.ptr(vals), n,
+                                                    m, W, Bv, st), "atomic")
+        K = np.zeros((n, n))
+        cols = plan.cols.cpu().numpy()
+        v = vals.cpu().numpy()[:, :, 0]
+        np.add.at(K, (np.tile(np.arange(n), W), cols.ravel()), v.ravel())
+        K = K[np.ix_(perm, perm)]
+        assert np.max(np.abs(K - g["K"])) < 1e-13 * np.max(np.abs(g["K"])), mode
+    f_nm = torch.from_numpy(g["f"][inv]).to(dev).reshape(n, 1).contiguous()
+    F = torch.empty((n, 1), dtype=T64, device=dev)
+    _hip.check(L.diffhe_ell_spmv_shared(_hip.ptr(plan.Mvals), _hip.ptr(plan.cols), _hip.ptr(f_nm), None, 1, None,
+                                        _hip.ptr(F), n, W, 1, st), "spmv")
+    assert np.max(np.abs(F.cpu().numpy()[perm, 0] - g["F"])) < 1e-14
+
+
+@pytest.mark.parametrize("name", golden_names("g9_batch_"))
+def test_batched_golden(name):
+    """Batch = loop of reference solves (G9): per-sample kappa (B,), f (B,n)."""
+    g = golden(name)
+    kappa = torch.from_numpy(g["kappa"]).clone().requires_grad_(True)
+    f = torch.from_numpy(g["f"]).clone().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh_from(g), kappa)
+    u = solver(f)
+    assert u.shape == g["u"].shape
+    (u ** 2).sum().backward()
+    assert rel_err(u.detach().numpy(), g["u"]) < RTOL_U
+    assert rel_err(kappa.grad.numpy(), g["dkappa"]) < RTOL_GRAD
+    assert rel_err(f.grad.numpy(), g["df"]) < RTOL_GRAD
+    # shared scalar kappa over a batch: gradient = sum over samples (all-reduce semantics)
+    k0 = torch.tensor(float(g["kappa"][0]), dtype=T64, requires_grad=True)
+    u0 = DifferentiableFESolver(mesh_from(g), k0)(torch.from_numpy(g["f"]))
+    (u0 ** 2).sum().backward()
+    ref = sum(orc.solve_with_adjoint(g["nodes"], g["elements"], g["bc_nodes"], g["bc_vals"], float(g["kappa"][0]),
+                                     g["f"][b], lambda u: 2 * u)[1].sum() for b in range(len(g["f"])))
+    assert abs(float(k0.grad) - ref) <= RTOL_GRAD * abs(ref)
+
+
+def test_reference_known_answers():
+    """reference tests/test_fem.py:85-179 run through the HIP path."""
+    for N, atol in ((10, 1e-10), (100, 1e-9)):
+        mesh = FEMesh.line(n_elements=N)
+        x = mesh.nodes.squeeze(1)
+        u = DifferentiableFESolver(mesh)(torch.ones_like(x))
+        assert torch.allclose(u, x * (1 - x) / 2, atol=atol)
+        assert abs(float(u[0])) < 1e-12 and abs(float(u[-1])) < 1e-12
+    errs = []
+    for N in (10, 20, 40, 80):
+        mesh = FEMesh.line(n_elements=N)
+        x = mesh.nodes.squeeze(1)
+        u = DifferentiableFESolver(mesh)((math.pi ** 2) * torch.sin(math.pi * x))
+        errs.append(float((u - torch.sin(math.pi * x)).abs().max()))
+    for a, b in zip(errs, errs[1:]):
+        assert a / (b + 1e-15) > 3.0
+    mesh = FEMesh.line(n_elements=10, bc_left=1.0, bc_right=2.0)
+    x = mesh.nodes.squeeze(1)
+    assert torch.allclose(DifferentiableFESolver(mesh)(torch.zeros_like(x)), 1.0 + x, atol=1e-10)
+    kappa = torch.tensor(1.0, dtype=T64, requires_grad=True)
+    mesh = FEMesh.line(n_elements=5)
+    DifferentiableFESolver(mesh, kappa=kappa)(torch.ones(6, dtype=T64)).sum().backward()
+    assert kappa.grad is not None and kappa.grad.abs() > 1e-10
+    mesh = FEMesh.rectangle(nx=4, ny=4)
+    assert DifferentiableFESolver(mesh)(torch.zeros(25, dtype=T64)).abs().max() < 1e-10
+    mesh = FEMesh.rectangle(nx=8, ny=8)
+    u = DifferentiableFESolver(mesh)(torch.ones(81, dtype=T64))
+    assert float(u[mesh.free_nodes()].min()) > 0.0
+    # f given as float32 / (n,1) works and returns float64
+    u32 = DifferentiableFESolver(mesh)(torch.ones(81, 1, dtype=torch.float32))
+    assert u32.dtype == T64 and torch.allclose(u32, u)
+
+
+@pytest.mark.parametrize("mk", [lambda: FEMesh.line(37, -1.0, 2.0, 0.3, -0.2), lambda: FEMesh.rectangle(7, 5, (0, 2), (0, 1), 0.1)])
+def test_per_element_kappa_vs_oracle(mk):
+    """Per-element kappa (documented by the reference, solver.py:28-29, but broken there)."""
+    mesh = mk()
+    nodes, el, bn, bv = arrays(mesh)
+    rng = np.random.default_rng(11)
+    B = 5
+    kap = np.exp(0.3 * rng.standard_normal((B, mesh.n_elements)))
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    # (m,) shared by the batch, and (B,m)
+    for kk, ff in ((kap[0], f), (kap, f), (kap[1], f[1])):
+        kt = torch.from_numpy(kk).clone().requires_grad_(True)
+        ft = torch.from_numpy(ff).clone().requires_grad_(True)
+        u = DifferentiableFESolver(mesh, kt)(ft)
+        (u ** 2).sum().backward()
+        fb = ff if ff.ndim == 2 else ff[None]
+        dk_ref = np.zeros_like(kk)
+        for b in range(len(fb)):
+            kb = kk[b] if kk.ndim == 2 else kk
+            uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kb, fb[b], lambda u: 2 * u)
+            ub = u[b] if u.dim() == 2 else u
+            assert rel_err(ub.detach().numpy(), uo) < RTOL_U
+            gf = ft.grad[b] if ft.grad.dim() == 2 else ft.grad
+            assert rel_err(gf.numpy(), dfo) < RTOL_GRAD
+            if kk.ndim == 2:
+                dk_ref[b] = dko
+            else:
+                dk_ref += dko
+        assert rel_err(kt.grad.numpy(), dk_ref) < RTOL_GRAD
+
+
+def test_chain_with_interior_and_one_sided_dirichlet():
+    rng = np.random.default_rng(5)
+    for bc in ({0: 1.0}, {12: -0.5}, {3: 0.2, 9: 1.0}, {0: 0.0, 5: 0.3, 12: 1.0}):
+        x = np.sort(rng.uniform(0, 2, 13))
+        mesh = FEMesh(nodes=torch.from_numpy(x[:, None]), elements=FEMesh.line(12).elements, dirichlet_nodes=dict(bc))
+        nodes, el, bn, bv = arrays(mesh)
+        kap = rng.uniform(0.5, 2.0, 12)
+        f = rng.standard_normal(13)
+        kt = torch.from_numpy(kap).requires_grad_(True)
+        ft = torch.from_numpy(f).requires_grad_(True)
+        solver = DifferentiableFESolver(mesh, kt)
+        u = solver(ft)
+        assert solver.last_info.path == "chain1d-scan"
+        (u ** 2).sum().backward()
+        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap, f, lambda u: 2 * u)
+        assert rel_err(u.detach().numpy(), uo) < RTOL_U
+        assert rel_err(kt.grad.numpy(), dko) < RTOL_GRAD
+        assert rel_err(ft.grad.numpy(), dfo) < RTOL_GRAD
+
+
+def test_unordered_1d_mesh_takes_general_path():
+    g = golden("g2_1d_fwd_010")
+    n = len(g["f"])
+    perm = np.random.default_rng(2).permutation(n)
+    inv = np.argsort(perm)
+    bc = {int(perm[k]): float(v) for k, v in zip(g["bc_nodes"], g["bc_vals"])}
+    mesh = FEMesh(nodes=torch.from_numpy(g["nodes"][inv]), elements=torch.from_numpy(perm[g["elements"]]),
+                  dirichlet_nodes=bc)
+    solver = DifferentiableFESolver(mesh, float(g["kappa"]))
+    u = solver(torch.from_numpy(g["f"][inv]))
+    assert solver.last_info.path == "ell-pcg"
+    assert rel_err(u.numpy()[perm], g["u"]) < RTOL_U
+
+
+def test_kappa_recovery_trajectory():
+    """examples/poisson_1d_demo.py:88-112 on the HIP path reproduces the reference run (G7)."""
+    g = golden("g7_kappa_recovery")
+    mesh = mesh_from(g)
+    f = torch.from_numpy(g["f"])
+    u_data = torch.from_numpy(g["u_data"])
+    k = torch.tensor(1.0, dtype=T64, requires_grad=True)
+    opt = torch.optim.Adam([k], lr=0.1)
+    for step in range(200):
+        opt.zero_grad()
+        u = DifferentiableFESolver(mesh, kappa=k.abs())(f)
+        loss = ((u - u_data) ** 2).mean()
+        loss.backward()
+        grad = float(k.grad)
+        opt.step()
+        if step in (0, 1, 2, 99, 199):
+            ref = g["traj"][step]
+            assert abs(float(loss) - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-20
+            assert abs(grad - ref[1]) <= 1e-9 * abs(ref[1]) + 1e-16
+            assert abs(float(k.detach()) - ref[2]) < 1e-9
+    assert abs(float(k.detach()) - 2.0) < 1e-4
+
+
+def test_physics_loss_fem_match_value_and_cache():
+    g = golden("g8_physics_loss")
+    mesh = mesh_from(g)
+    loss = PhysicsLoss(mesh, lambda x: torch.ones_like(x), mode="fem_match")
+    u_pred = torch.from_numpy(g["u_pred"]).requires_grad_(True)
+    v = loss(u_pred)
+    assert abs(float(v) - float(g["fem_match"])) < 1e-15
+    v.backward()
+    assert u_pred.grad is not None
+    target = loss.fem_target()
+    assert loss.fem_target() is target                          # cached: not re-solved
+
+
+def test_config2_shape_1d_10000():
+    """BASELINE config 2 shape: 1D 10 000 elements, RHS ensemble, fwd + adjoint."""
+    mesh = FEMesh.line(10_000)
+    nodes, el, bn, bv = arrays(mesh)
+    B = 64
+    gen = torch.Generator().manual_seed(1234)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    k = torch.tensor(1.0, dtype=T64, requires_grad=True)
+    fc = f.cuda().requires_grad_(True)
+    u = DifferentiableFESolver(mesh, k)(fc)
+    assert u.is_cuda
+    loss = 0.5 * (u ** 2).sum() / B
+    loss.backward()
+    dk = 0.0
+    for b in (0, 17, 63):
+        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, 1.0, f[b].numpy(), lambda u: u / B)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(fc.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
+    # analytic identity: dL/dkappa = -<gbar,u>/kappa (Appendix B)
+    ref = -float((u.detach() ** 2).sum() / B)
+    assert abs(float(k.grad) - ref) <= 1e-10 * abs(ref)
+    # f == 1: u = x(1-x)/2 at the nodes
+    x = mesh.nodes.squeeze(1)
+    u1 = DifferentiableFESolver(mesh)(torch.ones_like(x))
+    assert float((u1 - x * (1 - x) / 2).abs().max()) < 1e-10 * 0.125
+
+
+def test_2d_64_batch_vs_oracle():
+    mesh = FEMesh.rectangle(64, 64)
+    nodes, el, bn, bv = arrays(mesh)
+    B = 6
+    gen = torch.Generator().manual_seed(2024)
+    kap = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    kt = kap.clone().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(f)
+    (u ** 2).sum().backward()
+    assert solver.last_info.not_converged == 0
+    for b in range(B):
+        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, float(kap[b]), f[b].numpy(), lambda u: 2 * u)
+        assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+        assert abs(float(kt.grad[b]) - dko.sum()) <= RTOL_GRAD * abs(dko.sum())

@@ -1,0 +1,189 @@
+"""CPU tests of the host side: mesh factories against the reference's golden data,
+plan/pattern construction against the oracle, API quirks of the boundary
+(SURVEY 8(b)).  No HIP kernel runs here."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from diffhe import FEMesh, DifferentiableFESolver, PhysicsLoss, NeuralPDE
+from diffhe.plan import build_ell_pattern, chain_segments, padded_batch, _bc_arrays
+from diffhe.solver import _kappa_mode, K_SCALAR, K_SAMPLE, K_ELEM, K_SAMPLE_ELEM
+from oracle import p1_oracle as orc
+from _util import golden, golden_json
+
+
+def _arrays(mesh):
+    bc_nodes = np.array(list(mesh.dirichlet_nodes.keys()), dtype=np.int64)
+    bc_vals = np.array(list(mesh.dirichlet_nodes.values()), dtype=np.float64)
+    return mesh.nodes.numpy(), mesh.elements.numpy(), bc_nodes, bc_vals
+
+
+@pytest.mark.parametrize("name,mesh", [
+    ("line_10", lambda: FEMesh.line(10)),
+    ("line_7_shift", lambda: FEMesh.line(7, -1.0, 2.5, 0.25, None)),
+    ("rect_4_4", lambda: FEMesh.rectangle(4, 4)),
+    ("rect_3_2", lambda: FEMesh.rectangle(3, 2, (0.0, 3.0), (0.0, 1.0), 0.5)),
+])
+def test_mesh_factories_verbatim(name, mesh):
+    g = golden("g6_mesh_" + name)
+    m = mesh()
+    nodes, elements, bc_nodes, bc_vals = _arrays(m)
+    assert m.nodes.dtype == torch.float64 and m.elements.dtype == torch.int64
+    assert np.array_equal(nodes, g["nodes"])
+    assert np.array_equal(elements, g["elements"])
+    assert np.array_equal(bc_nodes, g["bc_nodes"])          # dict order too
+    assert np.array_equal(bc_vals, g["bc_vals"])
+    assert m.free_nodes() == g["free"].tolist()
+    assert repr(m) == str(g["repr"])
+
+
+def test_mesh_factories_sha256_of_large_meshes():
+    pins = golden_json("g6_mesh_sha256.json")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    for key, pin in pins.items():
+        kind, *dims = key.split("_")
+        m = FEMesh.line(int(dims[0])) if kind == "line" else FEMesh.rectangle(int(dims[0]), int(dims[1]))
+        nodes, elements, bc_nodes, _ = _arrays(m)
+        assert sha(nodes) == pin["nodes"], key
+        assert sha(elements) == pin["elements"], key
+        assert sha(bc_nodes) == pin["bc_nodes"], key
+
+
+def test_mesh_api_reference_tests():
+    """reference tests/test_fem.py:43-72."""
+    m = FEMesh.line(n_elements=10)
+    assert (m.n_nodes, m.n_elements, m.dim) == (11, 10, 1)
+    assert m.dirichlet_nodes[0] == 0.0 and m.dirichlet_nodes[10] == 0.0
+    free = m.free_nodes()
+    assert len(free) == 9 and 0 not in free and 10 not in free
+    assert abs(m.h() - 0.1) < 1e-15
+    m2 = FEMesh.rectangle(nx=4, ny=4)
+    assert (m2.n_nodes, m2.n_elements, m2.dim) == (25, 32, 2)
+    assert len(m2.dirichlet_nodes) == 16
+    with pytest.raises(NotImplementedError):
+        m2.h()
+
+
+def _emulate_gather(pat, local, kappa_e, n):
+    """numpy model of diffhe_ell_assemble_rows without BCs -> dense K."""
+    W, cols, ptr, contrib = pat["W"], pat["cols"], pat["ent_ptr"], pat["contrib"]
+    m = local.shape[1]
+    K = np.zeros((n, n))
+    e, pq = contrib >> 4, contrib & 15
+    term = kappa_e[e] * local[pq, e]
+    ent_of = np.repeat(np.arange(W * n), np.diff(ptr))
+    vals = np.bincount(ent_of, weights=term, minlength=W * n)
+    rows = np.tile(np.arange(n), W)
+    np.add.at(K, (rows, cols.ravel()), vals)
+    return K
+
+
+@pytest.mark.parametrize("mesh", [
+    lambda: FEMesh.rectangle(6, 6), lambda: FEMesh.rectangle(3, 2, (0.0, 3.0), (0.0, 1.0), 0.5),
+    lambda: FEMesh.line(9), lambda: FEMesh.rectangle(5, 3),
+])
+def test_ell_pattern_reproduces_dense_assembly(mesh):
+    m = mesh()
+    nodes, elements, _, _ = _arrays(m)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(m.n_nodes)                      # also an unstructured numbering
+    for el in (elements, perm[elements]):
+        nd = nodes if el is elements else nodes[np.argsort(perm)]
+        pat = build_ell_pattern(el, m.n_nodes)
+        k0, _ = orc.element_matrices(nd, el)
+        npe = el.shape[1]
+        local = k0.reshape(len(el), npe * npe).T.copy()
+        kap = rng.uniform(0.5, 2.0, len(el))
+        K = _emulate_gather(pat, local, kap, m.n_nodes)
+        Kref, _ = orc.assemble_dense(nd, el, kap, np.zeros(m.n_nodes))
+        assert np.max(np.abs(K - Kref)) < 1e-12 * np.max(np.abs(Kref))
+        assert np.array_equal(pat["cols"][0], np.arange(m.n_nodes))       # slot 0 = diagonal
+        # slot_of points at the entry holding (row, col) of every local (p, q)
+        for pq in range(npe * npe):
+            r, c = el[:, pq // npe], el[:, pq % npe]
+            assert np.array_equal(pat["cols"][pat["slot_of"][pq], r], c)
+
+
+def test_chain_segments():
+    bc = np.zeros(8, dtype=np.uint8)
+    assert chain_segments(8, bc).tolist() == [[0, 7, 0]]
+    bc[[0, 7]] = 1
+    assert chain_segments(8, bc).tolist() == [[0, 7, 3]]
+    bc[:] = 0
+    bc[[2, 5]] = 1
+    assert chain_segments(8, bc).tolist() == [[0, 2, 2], [2, 5, 3], [5, 7, 1]]
+    bc[:] = 0
+    bc[0] = 1
+    assert chain_segments(8, bc).tolist() == [[0, 7, 1]]
+
+
+def test_padded_batch():
+    assert [padded_batch(b) for b in (1, 2, 3, 5, 33, 64, 65, 128, 200, 256, 1000)] == \
+        [1, 2, 4, 8, 64, 64, 128, 128, 256, 256, 1024]
+
+
+def test_kappa_modes():
+    m = 32
+    assert _kappa_mode(torch.tensor(1.0), m, None)[0] == K_SCALAR
+    assert _kappa_mode(torch.ones(1), m, 7)[0] == K_SCALAR
+    assert _kappa_mode(torch.ones(m), m, None) == (K_ELEM, None)
+    assert _kappa_mode(torch.ones(m), m, 5) == (K_ELEM, None)
+    assert _kappa_mode(torch.ones(5), m, 5) == (K_SAMPLE, 5)
+    assert _kappa_mode(torch.ones(5, 1), m, None) == (K_SAMPLE, 5)
+    assert _kappa_mode(torch.ones(5, m), m, 5) == (K_SAMPLE_ELEM, 5)
+    with pytest.raises(ValueError):
+        _kappa_mode(torch.ones(5, 3), m, 5)
+
+
+def test_solver_boundary_quirks():
+    """kappa wrapping, Parameter registration, errors."""
+    mesh = FEMesh.line(5)
+    s = DifferentiableFESolver(mesh)
+    assert s.kappa.dtype == torch.float64 and s.kappa.dim() == 0 and float(s.kappa) == 1.0
+    assert list(s.parameters()) == []
+    p64 = torch.nn.Parameter(torch.tensor(2.0, dtype=torch.float64))
+    s2 = DifferentiableFESolver(mesh, p64)
+    assert [n for n, _ in s2.named_parameters()] == ["_kappa"] and s2.kappa is p64
+    p32 = torch.nn.Parameter(torch.tensor(2.0))
+    s3 = DifferentiableFESolver(mesh, p32)
+    assert list(s3.parameters()) == [] and s3.kappa.dtype == torch.float64 and s3.kappa.requires_grad
+    bad = FEMesh(nodes=torch.zeros(4, 3, dtype=torch.float64), elements=torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(NotImplementedError, match="Only 1D and 2D supported"):
+        DifferentiableFESolver(bad)(torch.zeros(4))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback():
+    s = DifferentiableFESolver(FEMesh.line(5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s(torch.ones(6, dtype=torch.float64))
+
+
+def test_physics_loss_modes():
+    mesh = FEMesh.line(10)
+    with pytest.raises(ValueError, match="Unknown mode: 'bogus'"):
+        PhysicsLoss(mesh, lambda x: x, mode="bogus")
+    g = golden("g8_physics_loss")
+    loss = PhysicsLoss(mesh, lambda x: torch.ones_like(x), mode="variational")
+    assert abs(float(loss(torch.from_numpy(g["u_pred"]))) - float(g["variational"])) < 1e-13
+
+
+def test_neural_pde_mask_and_shapes():
+    """reference tests/test_neural.py:21-37 (BC mask) without any solve."""
+    mesh = FEMesh.line(10)
+    model = NeuralPDE(mesh, hidden_dim=8, n_layers=2)
+    u = model()
+    assert u.shape == (11,) and u.dtype == torch.float64
+    assert abs(float(u[0])) < 1e-12 and abs(float(u[-1])) < 1e-12
+    m2 = NeuralPDE(FEMesh.rectangle(3, 3), hidden_dim=4, n_layers=1)
+    assert float(m2._mask.sum()) == 4.0
+    losses = model.train_pde(lambda x: torch.ones_like(x), n_epochs=5, mode="variational", verbose=False)
+    assert len(losses) == 5
+
+
+def test_bc_arrays():
+    mesh = FEMesh.line(4, bc_left=1.5, bc_right=None)
+    is_bc, g = _bc_arrays(mesh)
+    assert is_bc.tolist() == [1, 0, 0, 0, 0] and g.tolist() == [1.5, 0, 0, 0, 0]
