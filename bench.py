@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: differentiable 2D P1 Poisson solves/sec (fwd + adjoint).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric / SURVEY 8(d) C4): FEMesh.rectangle(1024, 1024), 256 samples
+per GPU, one scalar kappa_b ~ U(0.5, 2.0) per sample (seed 4096 + rank), f == 1,
+L = mean_b sum_i u_b[i]^2.  One "step" = assemble K(kappa_b), F; forward solve; dL/du;
+adjoint solve; dL/dkappa contraction -- for every sample of the batch.  Inputs are resident
+in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, RCCL), the
+batch is sharded (weak scaling: 256 per GPU), the only collective is the loss all-reduce.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
+dominant kernel and `cpu_baseline` (the CPU oracle timed on the host cores, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "difffe-physics-lab_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", type=int, default=1024, help="N of the N x N mesh (bench contract: 1024)")
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU (bench contract: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from diffhe import FEMesh, DifferentiableFESolver, _hip
+    from diffhe.plan import get_plan, padded_batch
+
+    N, B = args.mesh, args.batch
+    mesh = FEMesh.rectangle(N, N)
+    n = mesh.n_nodes
+    gen = torch.Generator().manual_seed(4096 + rank)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=torch.float64)).to(dev).requires_grad_(True)
+    f = torch.ones(B, n, dtype=torch.float64, device=dev)
+    solver = DifferentiableFESolver(mesh, kappa, device=dev)
+    plan = get_plan(mesh, dev)
+
+    iters = []
+
+    def step():
+        kappa.grad = None
+        u = solver(f)
+        loss = (u ** 2).sum(dim=1).mean()
+        loss.backward()
+        info = solver.last_info
+        iters.append((info.iterations, info.adj_iterations, info.max_relres, info.adj_max_relres,
+                      info.not_converged))
+        return loss.detach(), u
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, u = step()
+        if world > 1:
+            dist.all_reduce(loss)       # the only collective: scalar loss (per-sample kappa)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = world * B * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the batched operator apply of the CG loop ----
+        L = _hip.lib()
+        Bp = padded_batch(B)
+        roof = None
+        if not plan.is_chain:
+            W = plan.W
+            vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
+            x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+            y = torch.empty_like(x)
+            part = torch.empty(L.diffhe_grad_kappa_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+
+            def launch():
+                _hip.check(L.diffhe_ell_apply(_hip.ptr(vals), _hip.ptr(plan.cols), _hip.ptr(x), _hip.ptr(y),
+                                              _hip.ptr(part), n, W, Bp, Bp, st), "diffhe_ell_apply")
+            for _ in range(3):
+                launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.kernel_reps):
+                launch()
+            e1.record()
+            e1.synchronize()
+            dur = e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
+            alg_bytes = (8.0 * W + 16.0) * n * Bp       # read W values + p, write Ap
+            achieved = alg_bytes / dur / 1e9
+            roof = {"bound": "hbm", "kernel": "cg_spmv_kernel", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4)}
+            del vals, x, y, part
+
+        # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------
+        cpu = None
+        parity = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import p1_oracle as orc
+            bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
+            bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
+            nodes, elements = mesh.nodes.numpy(), mesh.elements.numpy()
+            kb = float(kappa[0].detach())
+            tc = time.perf_counter()
+            uo, dk, _ = orc.solve_with_adjoint(nodes, elements, bn, bv, kb, np.ones(n), lambda u_: 2 * u_ / B,
+                                               sparse=True)
+            tc = time.perf_counter() - tc
+            cpu = {"value": round(1.0 / tc, 4), "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"1 sample of the same workload ({N}x{N}, fwd+adjoint, scipy SuperLU), {tc:.1f} s"}
+            ug = u[0].detach().cpu().numpy()
+            parity = {"u_rel_err": float(np.max(np.abs(ug - uo)) / np.max(np.abs(uo))),
+                      "dkappa_rel_err": float(abs(float(kappa.grad[0]) - dk.sum()) / abs(dk.sum()))}
+
+        it = np.array(iters[-args.steps:] if args.steps else iters, dtype=np.float64)
+        out = {
+            "metric": "FEM solves/sec (fwd+adjoint), 2D P1 Poisson 1024^2 mesh, batch=256 per GPU",
+            "value": round(value, 4), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C4: rectangle({N},{N}), {B} samples/GPU, kappa_b~U(0.5,2) scalar per sample, "
+                                   f"f=1, L=mean_b sum u^2, fwd+adjoint", "mesh": f"{N}x{N}", "batch_per_gpu": B,
+                       "global_batch": B * world, "solver": solver.last_info.path, "tol": solver.tol,
+                       "parallelism": f"batch-sharded x{world}"},
+            "solver_iters": {"fwd": int(it[:, 0].max()), "adj": int(it[:, 1].max()),
+                             "max_relres_fwd": float(it[:, 2].max()), "max_relres_adj": float(it[:, 3].max()),
+                             "not_converged": int(it[:, 4].max())},
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

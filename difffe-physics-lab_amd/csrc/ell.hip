@@ -592,6 +592,16 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
   return DIFFHE_OK;
 }
 
+extern "C" int diffhe_ell_apply(const double* vals, const int* cols, const double* x, double* y, double* part, int n,
+                                int W, int Bp, int Bv, void* stream) {
+  if (!vals || !cols || !x || !y || !part || n < 1 || W < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
+  hipLaunchKernelGGL(cg_spmv_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, vals, cols, x, y,
+                     part, n, W, Bp, Bv);
+  return diffhe::check_launch();
+}
+
 extern "C" int diffhe_grad_kappa_blocks(int m, int Bp) { return (int)diffhe::node_grid(m, Bp).x; }
 
 extern "C" int diffhe_p1_grad_kappa(const int* elems, const double* k0, const double* lam, const double* u,

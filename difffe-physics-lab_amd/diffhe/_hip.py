@@ -28,6 +28,7 @@ SIGNATURES = {
     "diffhe_ell_spmv_shared": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "diffhe_cg_workspace_doubles": (_L, [_I, _I]),
     "diffhe_ell_cg_solve": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
+    "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "diffhe_to_node_major": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),

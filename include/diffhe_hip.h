@@ -138,6 +138,12 @@ int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, do
                         int Bv, double tol, int max_iter, int check_every, double* work, double* relres,
                         int* iters, int* status_host, void* stream);
 
+/* One application of the batched operator, y = A x, with the per-sample dots x.y left as
+ * block partials in `part` (diffhe_grad_kappa_blocks(n, Bp) * Bp doubles): the very kernel
+ * the CG loop launches once per iteration, exposed so it can be timed and tested alone. */
+int diffhe_ell_apply(const double* vals, const int* cols, const double* x, double* y, double* part, int n, int W,
+                     int Bp, int Bv, void* stream);
+
 /* dL/dkappa contraction (reverse of solver.py:89-92 / :137-140, Appendix A step 2):
  *   dk[e,b] = - sum_{p,q} lambda[elem_p,b] * k0[p*npe+q, e] * (u[elem_q,b] + g[elem_q])
  *   (u is the eliminated-system solution, 0 on Dirichlet nodes; g (n) adds the Dirichlet

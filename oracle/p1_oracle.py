@@ -303,3 +303,86 @@ def physics_loss_variational(nodes, bc_nodes, f, u_pred):
     else:
         res = np.zeros(1)
     return float(np.mean(res ** 2))
+
+
+# ---------------------------------------------------------------------------
+# Extended-precision reference for ill-conditioned 1D chains
+# ---------------------------------------------------------------------------
+
+def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None):
+    """The SAME discrete system as `assemble_dense` + `apply_bc_and_solve` for a chain mesh
+    (elements[e] = (e, e+1); reference solver.py:73-98, :153-183), but assembled and
+    LU-factorised (tridiagonal, no pivoting: the matrix is SPD) in numpy.longdouble.
+
+    Why: cond(K_free) ~ 0.4 N^2, so at N = 10^4 the fp64 LU the reference runs
+    (torch.linalg.solve, solver.py:174) is itself ~4e-10 away from the exact discrete
+    solution (measured: dense LAPACK and SuperLU agree with each other to 5e-15 and both
+    differ from this routine by 4.04e-10).  Parity at that size is judged against this
+    routine, and the fp64 oracle's own distance to it is reported next to ours.
+    Returns u (and, with gbar_fn, dkappa per element and df) as float64.
+    """
+    LD = np.longdouble
+    x = np.asarray(nodes, dtype=np.float64)[:, 0].astype(LD)
+    n = len(x)
+    h = x[1:] - x[:-1]                                   # solver.py:84-86
+    k = _kappa_per_element(kappa, n - 1).astype(LD) / h  # solver.py:88
+    w = np.zeros(n, dtype=LD)
+    w[:-1] += h / 2
+    w[1:] += h / 2                                       # solver.py:95-96
+    is_bc = np.zeros(n, dtype=bool)
+    g = np.zeros(n, dtype=LD)
+    is_bc[np.asarray(bc_nodes, dtype=np.int64)] = True
+    g[np.asarray(bc_nodes, dtype=np.int64)] = np.asarray(bc_vals, dtype=np.float64)
+    diag = np.zeros(n, dtype=LD)
+    diag[:-1] += k
+    diag[1:] += k                                        # solver.py:89,92
+    off = -k                                             # solver.py:90-91
+
+    def tri_solve(rhs):
+        """Thomas on the eliminated system: identity rows at Dirichlet nodes."""
+        d = diag.copy()
+        lo = off.copy()   # couples i+1 -> i  (sub-diagonal entry of row i+1)
+        up = off.copy()   # couples i -> i+1
+        r = rhs.copy()
+        for i in range(n):
+            if is_bc[i]:
+                d[i] = 1.0
+                if i > 0:
+                    lo[i - 1] = 0.0
+                if i < n - 1:
+                    up[i] = 0.0
+        for i in range(n - 1):      # also cut couplings INTO Dirichlet columns
+            if is_bc[i + 1]:
+                up[i] = 0.0
+            if is_bc[i]:
+                lo[i] = 0.0
+        for i in range(1, n):
+            mlt = lo[i - 1] / d[i - 1]
+            d[i] = d[i] - mlt * up[i - 1]
+            r[i] = r[i] - mlt * r[i - 1]
+        sol = np.zeros(n, dtype=LD)
+        sol[-1] = r[-1] / d[-1]
+        for i in range(n - 2, -1, -1):
+            sol[i] = (r[i] - up[i] * sol[i + 1]) / d[i]
+        return sol
+
+    F = np.asarray(f, dtype=np.float64).astype(LD) * w
+    rhs = F.copy()
+    # lifting: F_free -= K[free,bc] g  (solver.py:166-169)
+    for i in range(n):
+        if is_bc[i]:
+            continue
+        if i > 0 and is_bc[i - 1]:
+            rhs[i] -= off[i - 1] * g[i - 1]
+        if i < n - 1 and is_bc[i + 1]:
+            rhs[i] -= off[i] * g[i + 1]
+    rhs[is_bc] = 0.0
+    u = tri_solve(rhs) + g
+    if gbar_fn is None:
+        return u.astype(np.float64)
+    gb = np.asarray(gbar_fn(u.astype(np.float64)), dtype=np.float64).astype(LD)
+    gb[is_bc] = 0.0
+    lam = tri_solve(gb)
+    dk = -(lam[1:] - lam[:-1]) * (u[1:] - u[:-1]) / h
+    df = lam * w
+    return u.astype(np.float64), dk.astype(np.float64), df.astype(np.float64)

@@ -284,11 +284,18 @@ def test_config2_shape_1d_10000():
     assert u.is_cuda
     loss = 0.5 * (u ** 2).sum() / B
     loss.backward()
-    dk = 0.0
+    # cond(K) ~ 4e7 here: the fp64 LU the reference runs is itself ~4e-10 off the exact
+    # discrete solution (oracle/p1_oracle.py:chain_solve_longdouble), so parity at this size
+    # is judged against the extended-precision restatement; the fp64 oracle must agree with
+    # us no worse than it agrees with that.
     for b in (0, 17, 63):
-        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, 1.0, f[b].numpy(), lambda u: u / B)
-        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
-        assert rel_err(fc.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
+        ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, 1.0, f[b].numpy(), lambda u: u / B)
+        ub = u[b].detach().cpu().numpy()
+        assert rel_err(ub, ux) < RTOL_U
+        assert rel_err(fc.grad[b].cpu().numpy(), dfx) < RTOL_GRAD
+        if b == 0:
+            uo = orc.solve(nodes, el, bn, bv, 1.0, f[b].numpy(), sparse=True)
+            assert rel_err(ub, uo) <= 2.0 * rel_err(uo, ux) + 1e-12
     # analytic identity: dL/dkappa = -<gbar,u>/kappa (Appendix B)
     ref = -float((u.detach() ** 2).sum() / B)
     assert abs(float(k.grad) - ref) <= 1e-10 * abs(ref)

@@ -181,3 +181,15 @@ def test_kappa_recovery_trajectory():
             assert abs(loss - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-20
             assert abs(float(k) - ref[2]) < 1e-9
     assert abs(float(k) - 2.0) < 1e-4
+
+
+@pytest.mark.parametrize("name", golden_names("g3_1d_grad_"))
+def test_longdouble_chain_oracle_matches_reference(name):
+    """The extended-precision chain restatement is pinned to the same golden vectors."""
+    g = golden(name)
+    kind = str(g["loss_kind"])
+    u, dk, df = orc.chain_solve_longdouble(g["nodes"], g["bc_nodes"], g["bc_vals"], g["kappa"], g["f"],
+                                           lambda u: loss_grad(kind, u, g["data"]))
+    assert rel_err(u, g["u"]) < 1e-11
+    assert abs(dk.sum() - g["dkappa"]) <= 1e-11 * abs(g["dkappa"])
+    assert rel_err(df, g["df"]) < 1e-11
