@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void element_integrals_kernel(const double* __
 __global__ __launch_bounds__(256) void assemble_rows_kernel(
     const double* __restrict__ local, const double* __restrict__ kappa, i64 kse, i64 ksb,
     const int* __restrict__ ent_ptr, const int* __restrict__ contrib, const int* __restrict__ cols,
-    const unsigned char* __restrict__ is_bc, const double* __restrict__ g, double* __restrict__ vals,
-    double* __restrict__ lift, int n, int m, int W, int Bv) {
+    const int* __restrict__ store_slot, const unsigned char* __restrict__ is_bc, const double* __restrict__ g,
+    double* __restrict__ vals, double* __restrict__ lift, int n, int m, int W, int Bv) {
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
   for (int i = nm.node0; i < n; i += nm.stride) {
@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
     double lf = 0.0;
     for (int k = 0; k < W; ++k) {
       const i64 ent = (i64)k * n + i;
+      const int store = store_slot ? store_slot[k] : k;
+      const int j = cols[ent];
+      const bool col_bc = is_bc && j != i && is_bc[j];
+      // entries that are not stored (lower triangle of a symmetric format) only matter for the lift
+      if (store < 0 && (row_bc || !col_bc)) continue;
       const int c0 = ent_ptr[ent], c1 = ent_ptr[ent + 1];
       double v = 0.0;
       for (int c = c0; c < c1; ++c) {
@@ -79,16 +84,13 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
         const double kap = kappa ? kappa[(i64)e * kse + (i64)nm.b * ksb] : 1.0;
         v += kap * local[(i64)pq * m + e];  // K[p,q] += kappa * k0[p,q], solver.py:89-92/:137-140
       }
-      if (is_bc) {
-        const int j = cols[ent];
-        if (row_bc) {
-          v = (k == 0) ? 1.0 : 0.0;
-        } else if (j != i && is_bc[j]) {
-          lf += v * g[j];  // F_free -= K[free,bc] g, solver.py:166-169
-          v = 0.0;
-        }
+      if (row_bc) {
+        v = (k == 0) ? 1.0 : 0.0;
+      } else if (col_bc) {
+        lf += v * g[j];  // F_free -= K[free,bc] g, solver.py:166-169
+        v = 0.0;
       }
-      vals[ent * Bv + nm.b] = v;
+      if (store >= 0) vals[((i64)store * n + i) * Bv + nm.b] = v;
     }
     if (lift) lift[(i64)i * Bv + nm.b] = lf;
   }
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void apply_dirichlet_kernel(const int* __restr
 __global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restrict__ vals,
                                                            const int* __restrict__ cols, const double* __restrict__ x,
                                                            const double* __restrict__ sub, int sub_B,
+                                                           const double* __restrict__ sub_scale,
                                                            const unsigned char* __restrict__ is_bc,
                                                            double* __restrict__ y, int n, int W, int Bp) {
   const NodeMap nm = node_map(Bp);
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restri
       const i64 ent = (i64)k * n + i;
       acc += vals[ent] * x[(i64)cols[ent] * Bp + nm.b];
     }
-    if (sub) acc -= sub[(i64)i * sub_B + (sub_B == 1 ? 0 : nm.b)];
+    if (sub) acc -= (sub_scale ? sub_scale[nm.b] : 1.0) * sub[(i64)i * sub_B + (sub_B == 1 ? 0 : nm.b)];
     if (is_bc && is_bc[i]) acc = 0.0;
     y[(i64)i * Bp + nm.b] = acc;
   }
@@ -481,13 +484,13 @@ extern "C" int diffhe_p1_element_integrals(const double* coords, const int* elem
 
 extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long kappa_se,
                                         long long kappa_sb, const int* ent_ptr, const int* contrib, const int* cols,
-                                        const unsigned char* is_bc, const double* g, double* vals, double* lift, int n,
-                                        int m, int W, int Bv, void* stream) {
+                                        const int* store_slot, const unsigned char* is_bc, const double* g,
+                                        double* vals, double* lift, int n, int m, int W, int Bv, void* stream) {
   if (!local || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
   if (is_bc && !g) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
   hipLaunchKernelGGL(assemble_rows_kernel, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local, kappa,
-                     kappa_se, kappa_sb, ent_ptr, contrib, cols, is_bc, g, vals, lift, n, m, W, Bv);
+                     kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g, vals, lift, n, m, W, Bv);
   return diffhe::check_launch();
 }
 
@@ -515,13 +518,13 @@ extern "C" int diffhe_ell_apply_dirichlet(const int* cols, const unsigned char* 
 }
 
 extern "C" int diffhe_ell_spmv_shared(const double* vals, const int* cols, const double* x, const double* sub,
-                                      int sub_B, const unsigned char* is_bc, double* y, int n, int W, int Bp,
-                                      void* stream) {
+                                      int sub_B, const double* sub_scale, const unsigned char* is_bc, double* y,
+                                      int n, int W, int Bp, void* stream) {
   if (!vals || !cols || !x || !y || n < 1 || W < 1) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   hipLaunchKernelGGL(spmv_shared_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, vals, cols, x,
-                     sub, sub_B, is_bc, y, n, W, Bp);
+                     sub, sub_B, sub_scale, is_bc, y, n, W, Bp);
   return diffhe::check_launch();
 }
 

@@ -1,0 +1,492 @@
+// Lattice fast path: meshes with the connectivity of FEMesh.rectangle (reference mesh.py:79-121;
+// node positions may be arbitrary).  The assembled operator is a 7-point stencil, stored as
+// SYMMETRIC DIAGONALS (DIA-sym): D0[i] = K[i,i], D1[i] = K[i,i+1], D2[i] = K[i,i+W] (W = nx+1),
+// D3[i] = K[i,i+nx] (the quad diagonal b-d; dropped when all triangles are right-angled, where
+// it is exactly 0).  No column indices at all; batch-innermost (n, Bp) vectors as in ell.hip.
+//
+// Solver: batched CG preconditioned by one geometric-multigrid V-cycle (P1 interpolation on the
+// nested triangulations, R = P^T, re-discretised coarse operators = Galerkin for nested P1,
+// damped-Jacobi smoothing, nu_pre = nu_post so the preconditioner is symmetric).  Replaces
+// torch.linalg.solve of reference solver.py:174 (forward) and of its autograd backward (adjoint).
+//
+// Matrix sharing: Bv = Bp (one matrix per sample) or Bv = 1 (one matrix for the batch) with an
+// optional per-sample scale s_b on the free rows, K_b = s_b * K_1 -- the exact form of the
+// assembled operator when kappa is one scalar per sample (solver.py:88,139: k_e = kappa * k0_e).
+#include "common.h"
+
+namespace {
+
+using namespace diffhe;
+typedef long long i64;
+
+struct Level {
+  int nx, ny, n, W, nd;
+  const double* v;          // (nd, n, Bv)
+  const unsigned char* bc;  // (n)
+};
+
+__device__ inline int dia_off(const Level& L, int k) { return k == 1 ? 1 : (k == 2 ? L.W : L.nx); }
+
+// sum_j K[i,j] x[j] for sample b (unscaled)
+__device__ inline double dia_row(const Level& L, int Bv, int vb, const double* __restrict__ x, int i, int b, int Bp) {
+  const i64 n = L.n;
+  double acc = L.v[(i64)i * Bv + vb] * x[(i64)i * Bp + b];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    if (k < L.nd) {
+      const int off = dia_off(L, k);
+      if (i + off < L.n) acc += L.v[((i64)k * n + i) * Bv + vb] * x[(i64)(i + off) * Bp + b];
+      if (i - off >= 0) acc += L.v[((i64)k * n + (i - off)) * Bv + vb] * x[(i64)(i - off) * Bp + b];
+    }
+  }
+  return acc;
+}
+
+__device__ inline double row_scale(const Level& L, const double* __restrict__ scale, int i, int b) {
+  return (scale && !L.bc[i]) ? scale[b] : 1.0;
+}
+
+#define STORE_PARTIAL(part, val)                                                          \
+  do {                                                                                    \
+    const double t__ = block_sum_per_sample((val), Bp, lds);                              \
+    if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < (Bp < kWave ? Bp : kWave))        \
+      (part)[(i64)blockIdx.x * Bp + nm.b] = t__;                                          \
+  } while (0)
+
+// y = A x ; part = per-sample partial of x.y
+__global__ __launch_bounds__(256) void dia_apply_dot_kernel(Level L, int Bv, const double* __restrict__ scale,
+                                                             const double* __restrict__ x, double* __restrict__ y,
+                                                             double* __restrict__ part, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  for (int i = nm.node0; i < L.n; i += nm.stride) {
+    const double acc = row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
+    const i64 o = (i64)i * Bp + nm.b;
+    y[o] = acc;
+    s += acc * x[o];
+  }
+  STORE_PARTIAL(part, s);
+}
+
+// r = b - A x ; optional part = per-sample partial of r.r
+__global__ __launch_bounds__(256) void dia_residual_kernel(Level L, int Bv, const double* __restrict__ scale,
+                                                            const double* __restrict__ bvec,
+                                                            const double* __restrict__ x, double* __restrict__ r,
+                                                            double* __restrict__ part, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  for (int i = nm.node0; i < L.n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    const double ri = bvec[o] - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
+    if (r) r[o] = ri;
+    s += ri * ri;
+  }
+  if (part) STORE_PARTIAL(part, s);
+}
+
+// damped Jacobi: xout = xin + omega (b - A xin) / D   (xin == NULL: xin = 0)
+// optional part = per-sample partial of b.xout  (the r.z dot of the CG, fused into the last sweep)
+__global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const double* __restrict__ scale,
+                                                          const double* __restrict__ bvec,
+                                                          const double* __restrict__ xin, double* __restrict__ xout,
+                                                          double omega, double* __restrict__ part, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  for (int i = nm.node0; i < L.n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    const double sc = row_scale(L, scale, i, nm.b);
+    const double d = sc * L.v[(i64)i * Bv + vb];
+    const double bi = bvec[o];
+    double xo;
+    if (xin)
+      xo = xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) / d;
+    else
+      xo = omega * bi / d;
+    xout[o] = xo;
+    s += bi * xo;
+  }
+  if (part) STORE_PARTIAL(part, s);
+}
+
+// coarse rhs = P^T r (P = P1 interpolation on the nested triangulation), 0 on coarse Dirichlet rows
+__global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, const double* __restrict__ r,
+                                                           double* __restrict__ rc, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int I = nm.node0; I < C.n; I += nm.stride) {
+    double out = 0.0;
+    if (!C.bc[I]) {
+      const int ci = I / C.W, cj = I - ci * C.W;
+      const int fi = 2 * ci, fj = 2 * cj;
+      const i64 c = (i64)fi * F.W + fj;
+      double h = 0.0;
+      if (fj > 0) h += r[(c - 1) * Bp + nm.b];
+      if (fj < F.nx) h += r[(c + 1) * Bp + nm.b];
+      if (fi > 0) h += r[(c - F.W) * Bp + nm.b];
+      if (fi < F.ny) h += r[(c + F.W) * Bp + nm.b];
+      if (fi > 0 && fj < F.nx) h += r[(c - F.W + 1) * Bp + nm.b];
+      if (fi < F.ny && fj > 0) h += r[(c + F.W - 1) * Bp + nm.b];
+      out = r[c * Bp + nm.b] + 0.5 * h;
+    }
+    rc[(i64)I * Bp + nm.b] = out;
+  }
+}
+
+// x += P e  (0 on fine Dirichlet rows)
+__global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, const double* __restrict__ e,
+                                                              double* __restrict__ x, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int i = nm.node0; i < F.n; i += nm.stride) {
+    if (F.bc[i]) continue;
+    const int fi = i / F.W, fj = i - fi * F.W;
+    const int ci = fi >> 1, cj = fj >> 1;
+    const i64 c = (i64)ci * C.W + cj;
+    double v;
+    if (!(fi & 1) && !(fj & 1))
+      v = e[c * Bp + nm.b];
+    else if (!(fi & 1))
+      v = 0.5 * (e[c * Bp + nm.b] + e[(c + 1) * Bp + nm.b]);
+    else if (!(fj & 1))
+      v = 0.5 * (e[c * Bp + nm.b] + e[(c + C.W) * Bp + nm.b]);
+    else
+      v = 0.5 * (e[(c + 1) * Bp + nm.b] + e[(c + C.W) * Bp + nm.b]);  // midpoint of the quad diagonal b-d
+    x[(i64)i * Bp + nm.b] += v;
+  }
+}
+
+// per-element kappa of the coarse triangulation = mean of its 4 children (Galerkin for nested P1)
+__global__ __launch_bounds__(256) void mg_restrict_kappa_kernel(const double* __restrict__ kf, double* __restrict__ kc,
+                                                                 int nxc, int nyc, int Bv) {
+  const NodeMap nm = node_map(Bv);
+  const int mc = 2 * nxc * nyc, nxf = 2 * nxc;
+  for (int E = nm.node0; E < mc; E += nm.stride) {
+    const int q = E >> 1, up = E & 1;
+    const int I = q / nxc, J = q - I * nxc;
+    // fine element id = 2*(row*nxf + col) + upper
+    auto fe = [&](int r, int c, int u) { return (i64)(2 * ((i64)r * nxf + c) + u) * Bv + nm.b; };
+    double s;
+    if (!up)
+      s = kf[fe(2 * I, 2 * J, 0)] + kf[fe(2 * I, 2 * J, 1)] + kf[fe(2 * I, 2 * J + 1, 0)] + kf[fe(2 * I + 1, 2 * J, 0)];
+    else
+      s = kf[fe(2 * I + 1, 2 * J + 1, 1)] + kf[fe(2 * I + 1, 2 * J + 1, 0)] + kf[fe(2 * I, 2 * J + 1, 1)] +
+          kf[fe(2 * I + 1, 2 * J, 1)];
+    kc[(i64)E * Bv + nm.b] = 0.25 * s;
+  }
+}
+
+// ---- CG vector kernels ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
+                                                        double* __restrict__ r, double* __restrict__ part, int n,
+                                                        int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  double s = 0.0;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    const double bi = bvec[o];
+    x[o] = 0.0;
+    r[o] = bi;
+    s += bi * bi;
+  }
+  STORE_PARTIAL(part, s);
+}
+
+__global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
+                                                          const double* __restrict__ alpha, double* __restrict__ x,
+                                                          double* __restrict__ r, double* __restrict__ part, int n,
+                                                          int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const double a = alpha[nm.b];
+  double s = 0.0;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    x[o] += a * p[o];
+    const double ri = r[o] - a * Ap[o];
+    r[o] = ri;
+    s += ri * ri;
+  }
+  STORE_PARTIAL(part, s);
+}
+
+// p = z + beta p   (first: p = z)
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restrict__ z, const double* __restrict__ beta,
+                                                            double* __restrict__ p, int first, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  const double be = first ? 0.0 : beta[nm.b];
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    p[o] = first ? z[o] : z[o] + be * p[o];
+  }
+}
+
+// ---- per-sample scalars -----------------------------------------------------------------------
+struct PcgScalars {
+  double *rz, *alpha, *beta, *bb, *tol2;
+  int *active, *iters, *n_active;
+};
+enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5 };
+
+// 1024 threads: lanes over samples, 16 waves over slices of the partial list (fixed order)
+__global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const double* __restrict__ part, int nblk, int Bp,
+                                                           double tol, PcgScalars S, double* __restrict__ relres) {
+  __shared__ double lds[16 * kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWave + lane;
+  double s = 0.0;
+  if (b < Bp)
+    for (int k = wave; k < nblk; k += 16) s += part[(i64)k * Bp + b];
+  lds[wave * kWave + lane] = s;
+  __syncthreads();
+  if (wave != 0 || b >= Bp) return;
+  double a = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) a += lds[w * kWave + lane];
+  switch (phase) {
+    case S_INIT:  // a = b.b
+      S.bb[b] = a;
+      S.tol2[b] = tol * tol * a;
+      S.active[b] = a > 0.0 ? 1 : 0;
+      S.iters[b] = 0;
+      S.alpha[b] = 0.0;
+      S.beta[b] = 0.0;
+      S.rz[b] = 0.0;
+      break;
+    case S_RZ0:  // a = r.z
+      S.rz[b] = a;
+      break;
+    case S_ALPHA:  // a = p.Ap
+      S.alpha[b] = (S.active[b] && a > 0.0) ? S.rz[b] / a : 0.0;
+      if (b == 0) *S.n_active = 0;
+      break;
+    case S_CONV:  // a = r.r after the update
+      if (S.active[b]) {
+        S.iters[b] += 1;
+        if (a <= S.tol2[b])
+          S.active[b] = 0;
+        else
+          atomicAdd(S.n_active, 1);
+      }
+      break;
+    case S_BETA:  // a = r.z (new)
+      if (S.active[b]) {
+        S.beta[b] = a / S.rz[b];
+        S.rz[b] = a;
+      } else {
+        S.beta[b] = 0.0;
+      }
+      break;
+    default:  // S_RELRES: a = |b - A x|^2
+      relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
+  }
+}
+
+// ---- host-side hierarchy --------------------------------------------------------------------
+constexpr int kMaxLevels = 16;
+
+struct Hier {
+  Level lev[kMaxLevels];
+  int nl, Bv, Bp;
+  const double* scale;
+  double omega;
+  int nu, n_coarse;
+  // per-level work vectors
+  double *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];
+};
+
+inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
+
+#define LAUNCH(kernel, n, ...) hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__)
+
+// z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
+// fine sweep also leaves the partials of rhs0.z there.
+double* vcycle(const Hier& H, const double* rhs0, double* rz_part, hipStream_t st) {
+  const double* rhs[kMaxLevels];
+  double* cur[kMaxLevels];
+  rhs[0] = rhs0;
+  const int last = H.nl - 1;
+  // downward leg
+  for (int l = 0; l <= last; ++l) {
+    const Level& L = H.lev[l];
+    double* a = H.xa[l];
+    double* b2 = H.xb[l];
+    const int sweeps = (l == last) ? H.n_coarse : H.nu;
+    const bool only = (H.nl == 1);  // no coarse level: the V-cycle is `sweeps` Jacobi sweeps
+    LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)nullptr, a, H.omega,
+           (only && sweeps == 1) ? rz_part : (double*)nullptr, H.Bp);
+    for (int s = 1; s < sweeps; ++s) {
+      LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, b2, H.omega,
+             (only && s == sweeps - 1) ? rz_part : (double*)nullptr, H.Bp);
+      double* t = a; a = b2; b2 = t;
+    }
+    cur[l] = a;
+    if (l < last) {
+      LAUNCH(dia_residual_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, H.res[l], (double*)nullptr, H.Bp);
+      const Level& C = H.lev[l + 1];
+      LAUNCH(mg_restrict_kernel, C.n, L, C, (const double*)H.res[l], H.rhs[l + 1], H.Bp);
+      rhs[l + 1] = H.rhs[l + 1];
+    }
+  }
+  // upward leg
+  for (int l = last - 1; l >= 0; --l) {
+    const Level& L = H.lev[l];
+    const Level& C = H.lev[l + 1];
+    double* a = cur[l];
+    double* b2 = (a == H.xa[l]) ? H.xb[l] : H.xa[l];
+    LAUNCH(mg_prolong_add_kernel, L.n, L, C, (const double*)cur[l + 1], a, H.Bp);
+    for (int s = 0; s < H.nu; ++s) {
+      LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, b2, H.omega,
+             (l == 0 && s == H.nu - 1) ? rz_part : (double*)nullptr, H.Bp);
+      double* t = a; a = b2; b2 = t;
+    }
+    cur[l] = a;
+  }
+  return cur[0];
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int Bv, int Bp, const double* scale,
+                     double omega, int nu, int n_coarse) {
+  if (!levels || n_levels < 1 || n_levels > kMaxLevels) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
+  if (nu < 1 || n_coarse < 1) return DIFFHE_E_BADARG;
+  for (int l = 0; l < n_levels; ++l) {
+    const diffhe_mg_level& s = levels[l];
+    if (s.nx < 2 || s.ny < 2 || (s.nd != 3 && s.nd != 4) || !s.vals || !s.is_bc) return DIFFHE_E_BADARG;
+    if (l > 0 && (levels[l - 1].nx != 2 * s.nx || levels[l - 1].ny != 2 * s.ny)) return DIFFHE_E_BADARG;
+    if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
+    Level& L = H.lev[l];
+    L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
+    L.v = s.vals; L.bc = s.is_bc;
+  }
+  H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.omega = omega; H.nu = nu; H.n_coarse = n_coarse;
+  return DIFFHE_OK;
+}
+
+static long long carve(Hier& H, double* work) {
+  long long off = 0;
+  auto take = [&](long long cnt) { double* p = work ? work + off : nullptr; off += cnt; return p; };
+  for (int l = 0; l < H.nl; ++l) {
+    const long long nb = (long long)H.lev[l].n * H.Bp;
+    H.xa[l] = take(nb);
+    H.xb[l] = take(nb);
+    H.res[l] = take(nb);
+    H.rhs[l] = l > 0 ? take(nb) : nullptr;
+  }
+  return off;
+}
+
+extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp) {
+  Hier H;
+  if (fill_hier(H, levels, n_levels, 1, Bp, nullptr, 0.8, 1, 1)) return -1;
+  const long long nb = (long long)H.lev[0].n * Bp;
+  const long long nblk = lgrid(H.lev[0].n, Bp).x;
+  return carve(H, nullptr) + 3 * nb + 2 * nblk * Bp + 16LL * Bp + 64;
+}
+
+extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
+                                        const double* b, double* x, int Bp, double tol, int max_iter, int nu,
+                                        int n_coarse, double omega, double* work, double* relres, int* iters,
+                                        int* status_host, void* stream) {
+  if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0) return DIFFHE_E_BADARG;
+  Hier H;
+  int rc = fill_hier(H, levels, n_levels, Bv, Bp, scale, omega, nu, n_coarse);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const Level& L0 = H.lev[0];
+  const int n = L0.n;
+  const long long nb = (long long)n * Bp;
+  const int nblk = lgrid(n, Bp).x;
+  double* w = work + carve(H, work);
+  double* r = w;
+  double* p = r + nb;
+  double* Ap = p + nb;
+  double* partA = Ap + nb;
+  double* partB = partA + (long long)nblk * Bp;
+  double* sc = partB + (long long)nblk * Bp;
+  PcgScalars S;
+  S.rz = sc; S.alpha = sc + Bp; S.beta = sc + 2 * Bp; S.bb = sc + 3 * Bp; S.tol2 = sc + 4 * Bp;
+  S.active = (int*)(sc + 5 * Bp);
+  S.iters = iters;
+  S.n_active = (int*)(sc + 6 * Bp);
+  const dim3 sgrid((Bp + 63) / 64);
+#define SCALAR(phase, part) \
+  hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), nblk, Bp, tol, S, relres)
+
+  LAUNCH(pcg_init_kernel, n, b, x, r, partA, n, Bp);
+  SCALAR(S_INIT, partA);
+  double* z = vcycle(H, r, partB, st);
+  SCALAR(S_RZ0, partB);
+  LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 1, n, Bp);
+  rc = diffhe::check_launch();
+  if (rc) return rc;
+
+  int it = 0, n_active = -1;
+  while (it < max_iter) {
+    LAUNCH(dia_apply_dot_kernel, n, L0, Bv, scale, (const double*)p, Ap, partA, Bp);
+    SCALAR(S_ALPHA, partA);
+    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, x, r, partA, n, Bp);
+    SCALAR(S_CONV, partA);
+    ++it;
+    rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (rc) return rc;
+    // overlap the convergence read-back with the next V-cycle: enqueue it first, then wait
+    z = vcycle(H, r, partB, st);
+    SCALAR(S_BETA, partB);
+    LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 0, n, Bp);
+    rc = diffhe::check(hipStreamSynchronize(st));
+    if (rc) return rc;
+    n_active = status_host[2];
+    if (n_active == 0) break;
+  }
+  LAUNCH(dia_residual_kernel, n, L0, Bv, scale, b, (const double*)x, (double*)nullptr, partA, Bp);
+  SCALAR(S_RELRES, partA);
+  rc = diffhe::check_launch();
+  if (rc) return rc;
+  status_host[0] = it;
+  status_host[1] = n_active < 0 ? 0 : n_active;
+  return DIFFHE_OK;
+}
+
+extern "C" int diffhe_lattice_blocks(int n, int Bp) { return (int)lgrid(n, Bp).x; }
+
+extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
+                                    double* y, double* part, int Bp, void* stream) {
+  if (!x || !y || !part) return DIFFHE_E_BADARG;
+  Hier H;
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, 0.8, 1, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH(dia_apply_dot_kernel, H.lev[0].n, H.lev[0], Bv, scale, x, y, part, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,
+                                     const double* xin, double* xout, double omega, int Bp, void* stream) {
+  if (!rhs || !xout) return DIFFHE_E_BADARG;
+  Hier H;
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, omega, 1, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH(dia_jacobi_kernel, H.lev[0].n, H.lev[0], Bv, scale, rhs, xin, xout, omega, (double*)nullptr, Bp);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse,
+                                             int ny_coarse, int Bv, void* stream) {
+  if (!kappa_fine || !kappa_coarse || nx_coarse < 1 || ny_coarse < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  hipLaunchKernelGGL(mg_restrict_kappa_kernel, node_grid(2 * nx_coarse * ny_coarse, Bv), dim3(256), 0,
+                     (hipStream_t)stream, kappa_fine, kappa_coarse, nx_coarse, ny_coarse, Bv);
+  return diffhe::check_launch();
+}

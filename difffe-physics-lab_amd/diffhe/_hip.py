@@ -14,6 +14,14 @@ LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE),
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
 
+
+class MgLevel(C.Structure):
+    """struct diffhe_mg_level (include/diffhe_hip.h)."""
+    _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P)]
+
+
+_LV = C.POINTER(MgLevel)
+
 # name -> (restype, argtypes); must list every symbol of include/diffhe_hip.h
 SIGNATURES = {
     "diffhe_abi_version": (_I, []),
@@ -22,13 +30,19 @@ SIGNATURES = {
     "diffhe_chain1d_solve": (_I, [_P, _P, _L, _L, _P, _L, _P, _I, _P, _P, _L, _I, _I, _P, _P]),
     "diffhe_chain1d_adjoint": (_I, [_P, _P, _L, _L, _P, _L, _P, _L, _P, _I, _P, _L, _P, _L, _P, _I, _I, _P, _P]),
     "diffhe_p1_element_integrals": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
-    "diffhe_ell_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "diffhe_ell_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_atomic": (_I, [_P, _P, _I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_apply_dirichlet": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "diffhe_ell_spmv_shared": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "diffhe_ell_spmv_shared": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "diffhe_cg_workspace_doubles": (_L, [_I, _I]),
     "diffhe_ell_cg_solve": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "diffhe_lattice_pcg_workspace_doubles": (_L, [_LV, _I, _I]),
+    "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "diffhe_lattice_blocks": (_I, [_I, _I]),
+    "diffhe_lattice_apply": (_I, [_LV, _I, _P, _P, _P, _P, _I, _P]),
+    "diffhe_lattice_smooth": (_I, [_LV, _I, _P, _P, _P, _P, _D, _I, _P]),
+    "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "diffhe_to_node_major": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),

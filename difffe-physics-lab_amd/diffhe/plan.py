@@ -112,6 +112,93 @@ def build_ell_pattern(elements: np.ndarray, n: int):
                 slot_of=slot_of)
 
 
+def detect_lattice(elements: np.ndarray, n: int):
+    """(nx, ny) if `elements` is exactly the FEMesh.rectangle connectivity
+    (reference mesh.py:92-105: quad (a,b,c,d) -> [a,b,d], [b,c,d], row-major), else None."""
+    m = len(elements)
+    if elements.shape[1] != 3 or m < 8 or m % 2:
+        return None
+    nx = int(elements[0, 2]) - 1
+    if nx < 2 or (m // 2) % nx:
+        return None
+    ny = (m // 2) // nx
+    if ny < 2 or (nx + 1) * (ny + 1) != n:
+        return None
+    return (nx, ny) if np.array_equal(elements, lattice_elements(nx, ny)) else None
+
+
+def lattice_elements(nx: int, ny: int) -> np.ndarray:
+    row, col = np.divmod(np.arange(nx * ny, dtype=np.int64), nx)
+    a = row * (nx + 1) + col
+    tris = np.empty((2 * nx * ny, 3), dtype=np.int64)
+    tris[0::2, 0], tris[0::2, 1], tris[0::2, 2] = a, a + 1, a + nx + 1
+    tris[1::2, 0], tris[1::2, 1], tris[1::2, 2] = a + 1, a + nx + 2, a + nx + 1
+    return tris
+
+
+def build_dia_pattern(nx: int, ny: int):
+    """Gather lists of the symmetric-diagonal lattice format.
+
+    Seven entries per row in the fixed order offsets (0, +1, +W, +nx, -1, -W, -nx), W = nx+1;
+    the first four can be stored (store_slot), the lower three only feed the Dirichlet lift.
+    Returns dict(We=7, cols (7,n) i32, ent_ptr (7n+1) i32, contrib i32)."""
+    n, W = (nx + 1) * (ny + 1), nx + 1
+    el = lattice_elements(nx, ny)
+    m = len(el)
+    e_idx = np.repeat(np.arange(m, dtype=np.int64), 9)
+    pq = np.tile(np.arange(9, dtype=np.int64), m)
+    rows = el[e_idx, pq // 3]
+    cols = el[e_idx, pq % 3]
+    d = cols - rows
+    k = np.full(d.shape, -1, dtype=np.int64)
+    for kk, off in enumerate((0, 1, W, nx, -1, -W, -nx)):
+        k[d == off] = kk
+    assert (k >= 0).all()
+    ent = k * n + rows
+    ell_cols = np.tile(np.arange(n, dtype=np.int32), 7)
+    ell_cols[ent] = cols.astype(np.int32)
+    order = np.argsort(ent, kind="stable")
+    contrib = (e_idx * 16 + pq)[order].astype(np.int32)
+    ent_ptr = np.zeros(7 * n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ent, minlength=7 * n), out=ent_ptr[1:])
+    return dict(We=7, cols=ell_cols.reshape(7, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib)
+
+
+class LatticeLevel:
+    """One level of the multigrid hierarchy of a lattice mesh: geometry, element integrals
+    and gather lists on the device.  Level l uses every 2^l-th node of the fine mesh."""
+
+    def __init__(self, nodes2d: np.ndarray, is_bc2d: np.ndarray, device):
+        L = _hip.lib()
+        ny, nx = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
+        self.nx, self.ny = nx, ny
+        self.n, self.m = (nx + 1) * (ny + 1), 2 * nx * ny
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        self.coords = dev(nodes2d.reshape(self.n, 2).T)
+        self.elems = dev(lattice_elements(nx, ny).T.astype(np.int32))
+        self.is_bc = dev(is_bc2d.reshape(self.n).astype(np.uint8))
+        pat = build_dia_pattern(nx, ny)
+        self.cols, self.ent_ptr, self.contrib = dev(pat["cols"]), dev(pat["ent_ptr"]), dev(pat["contrib"])
+        self.k0 = torch.empty((9, self.m), dtype=torch.float64, device=device)
+        m0 = torch.empty((9, self.m), dtype=torch.float64, device=device)
+        _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), 2, self.n, self.m,
+                                                 _hip.ptr(self.k0), _hip.ptr(m0), _stream(device)),
+                   "diffhe_p1_element_integrals")
+        # quad-diagonal coupling b-d: local (1,2) of [a,b,d], local (0,2) of [b,c,d]; exactly 0 for
+        # right triangles (SURVEY section 0 fact 5) -> 3 stored diagonals instead of 4
+        hyp = max(float(self.k0[5, 0::2].abs().max()), float(self.k0[2, 1::2].abs().max()))
+        self.nd = 3 if hyp == 0.0 else 4
+        self.store_slot = dev(np.array([0, 1, 2, 3 if self.nd == 4 else -1, -1, -1, -1], dtype=np.int32))
+        self._zero_g = None
+        self._device = device
+
+    def zero_g(self):
+        """Dirichlet values of a coarse level: corrections vanish there."""
+        if self._zero_g is None:
+            self._zero_g = torch.zeros(self.n, dtype=torch.float64, device=self._device)
+        return self._zero_g
+
+
 class SolvePlan:
     """Device-resident metadata of one mesh (see module docstring)."""
 
@@ -138,6 +225,7 @@ class SolvePlan:
         self.pinned_status = torch.zeros(4, dtype=torch.int32).pin_memory()
 
         # --- 1D chain fast path ---------------------------------------------------------
+        self.is_lattice = False
         self.is_chain = bool(self.dim == 1 and self.n == self.m + 1
                              and np.array_equal(elements[:, 0], np.arange(self.m))
                              and np.array_equal(elements[:, 1], np.arange(1, self.m + 1)))
@@ -148,7 +236,22 @@ class SolvePlan:
             self.x = self.coords[0].contiguous()
             return
 
-        # --- general ELL path -----------------------------------------------------------
+        # --- lattice fast path: symmetric diagonals + multigrid hierarchy --------------------
+        self.levels = []
+        lat = detect_lattice(elements, self.n) if self.dim == 2 else None
+        self.is_lattice = lat is not None
+        if self.is_lattice:
+            nx, ny = lat
+            nodes2d = nodes.reshape(ny + 1, nx + 1, 2)
+            bc2d = is_bc.reshape(ny + 1, nx + 1)
+            while True:
+                self.levels.append(LatticeLevel(nodes2d, bc2d, device))
+                ny_l, nx_l = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
+                if nx_l % 2 or ny_l % 2 or min(nx_l, ny_l) < 4 or len(self.levels) >= 16:
+                    break
+                nodes2d, bc2d = nodes2d[::2, ::2], bc2d[::2, ::2]
+
+        # --- general ELL path (also provides the load matrix M of the lattice path) ---------
         pat = build_ell_pattern(elements, self.n)
         self.W = pat["W"]
         self.cols = dev(pat["cols"])
@@ -165,7 +268,7 @@ class SolvePlan:
         # load matrix M (batch-shared ELL values): F = M f, df = M^T lambda
         self.Mvals = torch.empty((self.W, self.n), dtype=torch.float64, device=device)
         _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self.m0), None, 0, 0, _hip.ptr(self.ent_ptr),
-                                              _hip.ptr(self.contrib), _hip.ptr(self.cols), None, None,
+                                              _hip.ptr(self.contrib), _hip.ptr(self.cols), None, None, None,
                                               _hip.ptr(self.Mvals), None, self.n, self.m, self.W, 1, stream),
                    "diffhe_ell_assemble_rows(M)")
 

@@ -128,24 +128,25 @@ class _Engine:
             lift.neg_()
         else:
             _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(p.k0), _hip.ptr(kdev), kse, ksb, _hip.ptr(p.ent_ptr),
-                                                  _hip.ptr(p.contrib), _hip.ptr(p.cols), _hip.ptr(p.is_bc),
+                                                  _hip.ptr(p.contrib), _hip.ptr(p.cols), None, _hip.ptr(p.is_bc),
                                                   _hip.ptr(p.g), _hip.ptr(vals), _hip.ptr(lift), p.n, p.m, p.W, Bv,
                                                   st), "diffhe_ell_assemble_rows")
         return vals, lift
 
-    def load_vector(self, f_nm, lift, Bv, Bp):
+    def load_vector(self, f_nm, lift, Bv, Bp, lift_scale=None):
+        """F = M f - lift_scale * lift on the free rows, 0 on Dirichlet rows."""
         p = self.p
         F = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
         _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(f_nm), _hip.ptr(lift),
-                                                 Bv, _hip.ptr(p.is_bc), _hip.ptr(F), p.n, p.W, Bp,
-                                                 _stream(p.device)), "diffhe_ell_spmv_shared")
+                                                 Bv, _hip.ptr(lift_scale), _hip.ptr(p.is_bc), _hip.ptr(F), p.n, p.W,
+                                                 Bp, _stream(p.device)), "diffhe_ell_spmv_shared")
         return F
 
     def apply_M(self, x_nm, Bp):
         p = self.p
         y = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
         _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(x_nm), None, 1, None,
-                                                 _hip.ptr(y), p.n, p.W, Bp, _stream(p.device)),
+                                                 None, _hip.ptr(y), p.n, p.W, Bp, _stream(p.device)),
                    "diffhe_ell_spmv_shared")
         return y
 
@@ -159,6 +160,71 @@ class _Engine:
                                          Bv, self.tol, self.max_iter, self.check_every, _hip.ptr(work),
                                          _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
                                          _stream(p.device)), "diffhe_ell_cg_solve")
+        st = p.pinned_status
+        return x, int(st[0]), int(st[1]), relres
+
+    # -- lattice path -----------------------------------------------------------------------
+    def lattice_assemble(self, kappa, mode, B, Bp):
+        """Per-level symmetric-diagonal operators.  -> (vals per level, Bv, scale, lift, lift_scale).
+
+        One scalar kappa per sample is kept factored, K_b = kappa_b * K_1 (solver.py:88,139 are
+        linear in kappa): ONE unit matrix per level is assembled for the whole batch and the
+        kernels scale the free rows by kappa_b."""
+        p, L = self.p, self.L
+        st = _stream(p.device)
+        k = kappa.detach().to(p.device, torch.float64)
+        scale = None
+        if mode == K_SCALAR:
+            kl, kse, ksb, Bv = k.reshape(1).contiguous(), 0, 0, 1
+        elif mode == K_SAMPLE:
+            kl, kse, ksb, Bv = None, 0, 0, 1
+            scale = torch.ones(Bp, dtype=torch.float64, device=p.device)
+            scale[:B] = k.reshape(B)
+        elif mode == K_ELEM:
+            kl, kse, ksb, Bv = k.reshape(p.m, 1).contiguous(), 1, 0, 1
+        else:
+            kl = self.to_node_major(k.reshape(B, p.m).contiguous(), B, Bp, p.m)
+            if Bp > B:
+                kl[:, B:] = 1.0
+            kse, ksb, Bv = Bp, 1, Bp
+        vals, lift = [], None
+        for li, lev in enumerate(p.levels):
+            if li > 0 and mode in (K_ELEM, K_SAMPLE_ELEM):   # coarse kappa = mean of the 4 children
+                kc = torch.empty((lev.m, Bv), dtype=torch.float64, device=p.device)
+                _hip.check(L.diffhe_lattice_restrict_kappa(_hip.ptr(kl), _hip.ptr(kc), lev.nx, lev.ny, Bv, st),
+                           "diffhe_lattice_restrict_kappa")
+                kl = kc
+            v = torch.empty((lev.nd, lev.n, Bv), dtype=torch.float64, device=p.device)
+            lf = torch.empty((lev.n, Bv), dtype=torch.float64, device=p.device) if li == 0 else None
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
+                                                  _hip.ptr(lev.contrib), _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
+                                                  _hip.ptr(lev.is_bc), _hip.ptr(p.g if li == 0 else lev.zero_g()),
+                                                  _hip.ptr(v), _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
+                       "diffhe_ell_assemble_rows(lattice)")
+            vals.append(v)
+            if li == 0:
+                lift = lf
+        return vals, Bv, scale, lift, scale
+
+    def lattice_levels(self, vals):
+        arr = (_hip.MgLevel * len(vals))()
+        for i, (lev, v) in enumerate(zip(self.p.levels, vals)):
+            arr[i].nx, arr[i].ny, arr[i].nd, arr[i].reserved = lev.nx, lev.ny, lev.nd, 0
+            arr[i].vals, arr[i].is_bc = v.data_ptr(), lev.is_bc.data_ptr()
+        return arr
+
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg):
+        p, L = self.p, self.L
+        arr = self.lattice_levels(vals)
+        nl = len(vals)
+        x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        work = torch.empty(L.diffhe_lattice_pcg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
+        relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
+                                              self.max_iter, mg["nu"], mg["n_coarse"], mg["omega"], _hip.ptr(work),
+                                              _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
+                                              _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
         return x, int(st[0]), int(st[1]), relres
 
@@ -209,6 +275,17 @@ class _FESolve(torch.autograd.Function):
                                               _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
                        "diffhe_chain1d_solve")
             ctx.saved = (kdev, ksb, kse, u)
+        elif plan.is_lattice and solver.method != "ell":
+            info.path = "lattice-mgpcg"
+            Bp = padded_batch(B)
+            vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
+            f_nm = eng.to_node_major(f_dev, B, Bp, n)
+            rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale)
+            x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg)
+            info.iterations, info.not_converged = its, bad
+            info.max_relres = float(relres[:B].max())
+            u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+            ctx.saved = (vals, x, Bp, Bv, scale)
         else:
             info.path = "ell-pcg"
             Bp = padded_batch(B)
@@ -220,8 +297,9 @@ class _FESolve(torch.autograd.Function):
             info.iterations, info.not_converged = its, bad
             info.max_relres = float(relres[:B].max())
             u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
-            ctx.saved = (vals, x, Bp, Bv)
+            ctx.saved = (vals, x, Bp, Bv, None)
         solver.last_info = info
+        ctx.path = info.path
         out = u if batched or B > 1 else u[0]
         return out.to(out_device)
 
@@ -249,9 +327,12 @@ class _FESolve(torch.autograd.Function):
             dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
             dk_elem = dk_e
         else:
-            vals, x, Bp, Bv = ctx.saved
+            vals, x, Bp, Bv, scale = ctx.saved
             rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
-            lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+            if ctx.path == "lattice-mgpcg":
+                lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.solver.mg)
+            else:
+                lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
             info.adj_iterations = its
             info.adj_max_relres = float(relres[:B].max())
             info.not_converged += bad
@@ -288,12 +369,15 @@ class DifferentiableFESolver(nn.Module):
     ----------
     mesh : FEMesh
     kappa : float or torch.Tensor -- diffusion coefficient (see module docstring).
-    device, tol, max_iter, check_every, assembly : HIP-path knobs (ours; the
-        reference has none).  `assembly` is "gather" (deterministic) or "atomic".
+    device, tol, max_iter, check_every, assembly, method, mg : HIP-path knobs (ours; the
+        reference has none).  `assembly` is "gather" (deterministic) or "atomic" (general
+        path); `method="ell"` forces the general ELL path on lattice meshes; `mg` overrides
+        the multigrid parameters (nu, n_coarse, omega) of the lattice path.
     """
 
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: float = 1e-12,
-                 max_iter: int = 20000, check_every: int = 25, assembly: str = "gather"):
+                 max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
+                 mg: Optional[dict] = None):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -302,6 +386,11 @@ class DifferentiableFESolver(nn.Module):
             self._kappa = kappa.to(dtype=torch.float64)                  # reference solver.py:38-39
         if assembly not in ("gather", "atomic"):
             raise ValueError(f"Unknown assembly: {assembly!r}")
+        if method not in ("auto", "ell"):
+            raise ValueError(f"Unknown method: {method!r}")
+        self.method = method      # "ell" forces the general path on lattice meshes
+        self.mg = dict(nu=2, n_coarse=8, omega=0.8)
+        self.mg.update(mg or {})
         self._device = device
         self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
         self.last_info = SolveInfo()

@@ -93,16 +93,20 @@ int diffhe_p1_element_integrals(const double* coords, const int* elems, int dim,
  *   kappa     kappa[e*kappa_se + b*kappa_sb] or NULL for kappa == 1
  *   ent_ptr   (n*W + 1) CSR over ELL entries (row i, slot k) -> contributions
  *   contrib   packed (e * 16 + p*npe+q)
- *   cols      (W, n) ELL column ids, slot 0 = diagonal, padding = own row
+ *   cols      (W, n) column id of entry (row i, k) at k*n + i; entry 0 = diagonal;
+ *             unused entries point at the row itself
+ *   store_slot (W) or NULL: entry k is stored at vals[(store_slot[k], i, b)]; -1 = not
+ *             stored (lower triangle of the symmetric-diagonal lattice format: such
+ *             entries only feed the Dirichlet lift).  NULL = identity (ELL).
  *   is_bc     (n) bytes or NULL (no elimination: raw K);  g (n) Dirichlet values
  *   vals      out (W, n, Bv); Bv = padded batch, or 1 when kappa is batch-shared
  *   lift      out (n, Bv) or NULL: lift_i = sum_{j in bc} K_ij g_j (0 on Dirichlet rows);
  *             Dirichlet rows become identity rows, couplings to Dirichlet columns 0.
  */
 int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long kappa_se, long long kappa_sb,
-                             const int* ent_ptr, const int* contrib, const int* cols, const unsigned char* is_bc,
-                             const double* g, double* vals, double* lift, int n, int m, int W, int Bv,
-                             void* stream);
+                             const int* ent_ptr, const int* contrib, const int* cols, const int* store_slot,
+                             const unsigned char* is_bc, const double* g, double* vals, double* lift, int n, int m,
+                             int W, int Bv, void* stream);
 
 /* Element-parallel assembly with fp64 global atomics (the literal scatter-add of
  * solver.py:89-92 / :137-140): element integrals are computed from coords and
@@ -117,12 +121,13 @@ int diffhe_ell_assemble_atomic(const double* coords, const int* elems, int dim, 
 int diffhe_ell_apply_dirichlet(const int* cols, const unsigned char* is_bc, const double* g, double* vals,
                                double* F, int n, int W, int Bp, void* stream);
 
-/* y = is_bc ? 0 : (M x - sub) for a batch-shared ELL matrix (values (W, n)): the
+/* y = is_bc ? 0 : (M x - sub_scale[b] * sub) for a batch-shared ELL matrix (values (W, n)): the
  * load vector F = M f (solver.py:95-96 / :143-145) minus the Dirichlet lift
  * (solver.py:166-169), and the adjoint df = M^T lambda (M symmetric; sub = is_bc = NULL).
- *   sub (n, sub_B) with sub_B == Bp or 1 (batch-shared), or NULL */
+ *   sub (n, sub_B) with sub_B == Bp or 1 (batch-shared), or NULL; sub_scale (Bp) or NULL (= 1) */
 int diffhe_ell_spmv_shared(const double* vals, const int* cols, const double* x, const double* sub, int sub_B,
-                           const unsigned char* is_bc, double* y, int n, int W, int Bp, void* stream);
+                           const double* sub_scale, const unsigned char* is_bc, double* y, int n, int W, int Bp,
+                           void* stream);
 
 /* Batched Jacobi-preconditioned CG on (W, n, Bv) ELL values, all samples at once.
  * Replaces torch.linalg.solve (solver.py:174) and, for the adjoint, the solve in
@@ -143,6 +148,46 @@ int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, do
  * the CG loop launches once per iteration, exposed so it can be timed and tested alone. */
 int diffhe_ell_apply(const double* vals, const int* cols, const double* x, double* y, double* part, int n, int W,
                      int Bp, int Bv, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Lattice fast path: meshes with the connectivity of FEMesh.rectangle (mesh.py:100-105).
+ * Operator = symmetric diagonals D0 (i,i), D1 (i,i+1), D2 (i,i+nx+1), D3 (i,i+nx; only when
+ * nd == 4), values (nd, n, Bv) produced by diffhe_ell_assemble_rows with
+ * store_slot = {0,1,2,3|-1,-1,-1,-1}.  Level l+1 is the 2:1 coarsening of level l.
+ * ---------------------------------------------------------------------------- */
+typedef struct diffhe_mg_level {
+  int nx, ny;                  /* elements per direction; n = (nx+1)*(ny+1) */
+  int nd;                      /* stored diagonals: 3 or 4 */
+  int reserved;
+  const double* vals;          /* (nd, n, Bv) */
+  const unsigned char* is_bc;  /* (n) */
+} diffhe_mg_level;
+
+/* Batched CG preconditioned by one multigrid V(nu,nu) cycle (damped Jacobi omega, P1
+ * transfers, n_coarse sweeps on the last level; n_levels == 1 degenerates to a Jacobi
+ * polynomial).  Replaces torch.linalg.solve (solver.py:174) forward and adjoint.
+ *   levels   HOST array of n_levels descriptors (device pointers inside)
+ *   Bv       Bp (matrix per sample) or 1 (shared); scale (Bp) or NULL: K_b = scale[b]*K on
+ *            the free rows (one scalar kappa per sample, solver.py:88,139)
+ *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
+ *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
+ *   relres, iters, status_host: as diffhe_ell_cg_solve */
+long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp);
+int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
+                             const double* b, double* x, int Bp, double tol, int max_iter, int nu, int n_coarse,
+                             double omega, double* work, double* relres, int* iters, int* status_host,
+                             void* stream);
+/* Single kernels of that loop, exposed for timing/tests: y = A x (+ x.y block partials in
+ * `part`, diffhe_lattice_blocks(n, Bp) * Bp doubles) and one damped-Jacobi sweep
+ * xout = xin + omega (rhs - A xin)/D  (xin NULL = 0). */
+int diffhe_lattice_blocks(int n, int Bp);
+int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x, double* y,
+                         double* part, int Bp, void* stream);
+int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,
+                          const double* xin, double* xout, double omega, int Bp, void* stream);
+/* kappa_coarse[E] = mean of the 4 children of coarse triangle E; arrays (m, Bv). */
+int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
+                                  int Bv, void* stream);
 
 /* dL/dkappa contraction (reverse of solver.py:89-92 / :137-140, Appendix A step 2):
  *   dk[e,b] = - sum_{p,q} lambda[elem_p,b] * k0[p*npe+q, e] * (u[elem_q,b] + g[elem_q])

@@ -55,15 +55,17 @@ def test_forward_golden(name):
         assert np.max(np.abs(u.numpy() - g["exact"])) < 1e-12
 
 
-@pytest.mark.parametrize("assembly", ["gather", "atomic"])
+@pytest.mark.parametrize("assembly,method", [("gather", "auto"), ("gather", "ell"), ("atomic", "ell")])
 @pytest.mark.parametrize("name", golden_names("g3_1d_grad_") + golden_names("g4_2d_0"))
-def test_gradients_golden(name, assembly):
+def test_gradients_golden(name, assembly, method):
     g = golden(name)
     kind = str(g["loss_kind"])
     kappa = torch.tensor(float(g["kappa"]), dtype=T64, requires_grad=True)
     f = torch.from_numpy(g["f"]).clone().requires_grad_(True)
-    solver = DifferentiableFESolver(mesh_from(g), kappa, assembly=assembly)
+    solver = DifferentiableFESolver(mesh_from(g), kappa, assembly=assembly, method=method)
     u = solver(f)
+    if name.startswith("g4"):
+        assert solver.last_info.path == ("lattice-mgpcg" if method == "auto" else "ell-pcg")
     loss = torch_loss(kind, u, g.get("data"))
     loss.backward()
     assert rel_err(u.detach().numpy(), g["u"]) < RTOL_U
@@ -96,7 +98,7 @@ def test_assembled_system_golden(name):
         vals = torch.zeros((W, n, Bv), dtype=T64, device=dev)
         if mode == "gather":
             _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(plan.k0), _hip.ptr(kap), 0, 0, _hip.ptr(plan.ent_ptr),
-                                                  _hip.ptr(plan.contrib), _hip.ptr(plan.cols), None, None,
+                                                  _hip.ptr(plan.contrib), _hip.ptr(plan.cols), None, None, None,
                                                   _hip.ptr(vals), None, n, m, W, Bv, st), "rows")
         else:
             _hip.check(L.diffhe_ell_assemble_atomic(_hip.ptr(plan.coords), _hip.ptr(plan.elems), plan.dim,
@@ -111,17 +113,18 @@ def test_assembled_system_golden(name):
     f_nm = torch.from_numpy(g["f"][inv]).to(dev).reshape(n, 1).contiguous()
     F = torch.empty((n, 1), dtype=T64, device=dev)
     _hip.check(L.diffhe_ell_spmv_shared(_hip.ptr(plan.Mvals), _hip.ptr(plan.cols), _hip.ptr(f_nm), None, 1, None,
-                                        _hip.ptr(F), n, W, 1, st), "spmv")
+                                        None, _hip.ptr(F), n, W, 1, st), "spmv")
     assert np.max(np.abs(F.cpu().numpy()[perm, 0] - g["F"])) < 1e-14
 
 
+@pytest.mark.parametrize("method", ["auto", "ell"])
 @pytest.mark.parametrize("name", golden_names("g9_batch_"))
-def test_batched_golden(name):
+def test_batched_golden(name, method):
     """Batch = loop of reference solves (G9): per-sample kappa (B,), f (B,n)."""
     g = golden(name)
     kappa = torch.from_numpy(g["kappa"]).clone().requires_grad_(True)
     f = torch.from_numpy(g["f"]).clone().requires_grad_(True)
-    solver = DifferentiableFESolver(mesh_from(g), kappa)
+    solver = DifferentiableFESolver(mesh_from(g), kappa, method=method)
     u = solver(f)
     assert u.shape == g["u"].shape
     (u ** 2).sum().backward()
@@ -130,7 +133,7 @@ def test_batched_golden(name):
     assert rel_err(f.grad.numpy(), g["df"]) < RTOL_GRAD
     # shared scalar kappa over a batch: gradient = sum over samples (all-reduce semantics)
     k0 = torch.tensor(float(g["kappa"][0]), dtype=T64, requires_grad=True)
-    u0 = DifferentiableFESolver(mesh_from(g), k0)(torch.from_numpy(g["f"]))
+    u0 = DifferentiableFESolver(mesh_from(g), k0, method=method)(torch.from_numpy(g["f"]))
     (u0 ** 2).sum().backward()
     ref = sum(orc.solve_with_adjoint(g["nodes"], g["elements"], g["bc_nodes"], g["bc_vals"], float(g["kappa"][0]),
                                      g["f"][b], lambda u: 2 * u)[1].sum() for b in range(len(g["f"])))
@@ -305,7 +308,37 @@ def test_config2_shape_1d_10000():
     assert float((u1 - x * (1 - x) / 2).abs().max()) < 1e-10 * 0.125
 
 
-def test_2d_64_batch_vs_oracle():
+def test_lattice_graded_mesh_and_per_element_kappa_all_levels():
+    """Lattice connectivity with NON-uniform node positions (4 stored diagonals: the quad
+    diagonal coupling is non-zero) and per-sample per-element kappa through 4 multigrid levels."""
+    nx, ny = 24, 16
+    base = FEMesh.rectangle(nx, ny, (0.0, 2.0), (0.0, 1.0), 0.3)
+    rng = np.random.default_rng(9)
+    xy = base.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
+    xy[1:-1, 1:-1] += rng.uniform(-0.2, 0.2, (ny - 1, nx - 1, 2)) * np.array([2.0 / nx, 1.0 / ny])
+    mesh = FEMesh(nodes=torch.from_numpy(xy.reshape(-1, 2)), elements=base.elements,
+                  dirichlet_nodes=dict(base.dirichlet_nodes))
+    nodes, el, bn, bv = arrays(mesh)
+    B = 3
+    kap = np.exp(0.5 * rng.standard_normal((B, mesh.n_elements)))
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    kt = torch.from_numpy(kap).requires_grad_(True)
+    ft = torch.from_numpy(f).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(ft)
+    assert solver.last_info.path == "lattice-mgpcg" and get_plan(mesh, torch.device("cuda", 0)).levels[0].nd == 4
+    assert len(get_plan(mesh, torch.device("cuda", 0)).levels) == 4
+    (u ** 2).sum().backward()
+    for b in range(B):
+        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
+        assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+        assert rel_err(kt.grad[b].numpy(), dko) < RTOL_GRAD
+        assert rel_err(ft.grad[b].numpy(), dfo) < RTOL_GRAD
+    assert solver.last_info.iterations < 40      # multigrid, not plain CG
+
+
+@pytest.mark.parametrize("method", ["auto", "ell"])
+def test_2d_64_batch_vs_oracle(method):
     mesh = FEMesh.rectangle(64, 64)
     nodes, el, bn, bv = arrays(mesh)
     B = 6
@@ -313,7 +346,7 @@ def test_2d_64_batch_vs_oracle():
     kap = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
     f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
     kt = kap.clone().requires_grad_(True)
-    solver = DifferentiableFESolver(mesh, kt)
+    solver = DifferentiableFESolver(mesh, kt, method=method)
     u = solver(f)
     (u ** 2).sum().backward()
     assert solver.last_info.not_converged == 0

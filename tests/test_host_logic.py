@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from diffhe import FEMesh, DifferentiableFESolver, PhysicsLoss, NeuralPDE
-from diffhe.plan import build_ell_pattern, chain_segments, padded_batch, _bc_arrays
+from diffhe.plan import (build_ell_pattern, build_dia_pattern, detect_lattice, lattice_elements, chain_segments,
+                         padded_batch, _bc_arrays)
 from diffhe.solver import _kappa_mode, K_SCALAR, K_SAMPLE, K_ELEM, K_SAMPLE_ELEM
 from oracle import p1_oracle as orc
 from _util import golden, golden_json
@@ -104,6 +105,40 @@ def test_ell_pattern_reproduces_dense_assembly(mesh):
         for pq in range(npe * npe):
             r, c = el[:, pq // npe], el[:, pq % npe]
             assert np.array_equal(pat["cols"][pat["slot_of"][pq], r], c)
+
+
+@pytest.mark.parametrize("nx,ny", [(2, 2), (5, 3), (8, 6)])
+def test_dia_pattern_reproduces_dense_assembly(nx, ny):
+    """numpy model of the symmetric-diagonal gather (store_slot semantics) vs the oracle."""
+    m = FEMesh.rectangle(nx, ny, (0.0, 2.0), (0.0, 1.0))
+    nodes, elements, _, _ = _arrays(m)
+    rng = np.random.default_rng(4)
+    nodes = nodes + rng.uniform(-0.05, 0.05, nodes.shape)          # skewed: all 4 diagonals live
+    assert detect_lattice(elements, m.n_nodes) == (nx, ny)
+    assert np.array_equal(lattice_elements(nx, ny), elements)
+    assert detect_lattice(elements[::-1].copy(), m.n_nodes) is None
+    pat = build_dia_pattern(nx, ny)
+    n, W = m.n_nodes, nx + 1
+    k0, _ = orc.element_matrices(nodes, elements)
+    local = k0.reshape(len(elements), 9).T.copy()
+    kap = rng.uniform(0.5, 2.0, len(elements))
+    e, pq = pat["contrib"] >> 4, pat["contrib"] & 15
+    ent_of = np.repeat(np.arange(7 * n), np.diff(pat["ent_ptr"]))
+    vals = np.bincount(ent_of, weights=kap[e] * local[pq, e], minlength=7 * n).reshape(7, n)
+    Kref, _ = orc.assemble_dense(nodes, elements, kap, np.zeros(n))
+    K = np.zeros((n, n))
+    for k, off in enumerate((0, 1, W, nx)):                         # stored upper diagonals
+        idx = np.arange(n - off)
+        K[idx, idx + off] += vals[k, : n - off]
+        if off:
+            K[idx + off, idx] += vals[k, : n - off]
+    assert np.max(np.abs(K - Kref)) < 1e-12 * np.max(np.abs(Kref))
+    for k, off in enumerate((0, 1, W, nx, -1, -W, -nx)):            # every entry = K[i, i+off]
+        i = np.arange(max(0, -off), min(n, n - off))
+        assert np.max(np.abs(vals[k, i] - Kref[i, i + off])) < 1e-12 * np.max(np.abs(Kref))
+        used = np.diff(pat["ent_ptr"]).reshape(7, n)[k] > 0
+        assert np.array_equal(pat["cols"][k][used], np.nonzero(used)[0] + off)
+        assert np.array_equal(pat["cols"][k][~used], np.nonzero(~used)[0])
 
 
 def test_chain_segments():
