@@ -12,6 +12,8 @@
 // Matrix sharing: Bv = Bp (one matrix per sample) or Bv = 1 (one matrix for the batch) with an
 // optional per-sample scale s_b on the free rows, K_b = s_b * K_1 -- the exact form of the
 // assembled operator when kappa is one scalar per sample (solver.py:88,139: k_e = kappa * k0_e).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -112,6 +114,211 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
     s += bi * xo;
   }
   if (part) STORE_PARTIAL(part, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strip kernels: the same three stencil operations with register-level reuse.
+//
+// A wave owns RW consecutive grid COLUMNS x 64 samples (lanes) and marches down the rows of its
+// tile keeping a 3-row window of x in registers: every x value is loaded once per wave (plus
+// the 2 halo columns per strip, (RW+2)/RW loads per output) instead of once per stencil leg;
+// the 4 waves of a block own 4 adjacent strips, so halo columns hit L1/L2.  Along a row the
+// coefficients of a strip are CONTIGUOUS, so with a batch-shared matrix (Bv == 1) they arrive
+// as a handful of wide scalar loads per row (s_load_dwordx16) -- no per-lane traffic at all.
+//
+// Invariant relied upon (and kept by every kernel of the solver): all vectors vanish on
+// Dirichlet rows, whose matrix rows are identity rows.  It lets the per-sample scale s_b be
+// applied to every row without looking up the Dirichlet flag (0 * s_b == 0).
+// ---------------------------------------------------------------------------------------------
+enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
+
+template <int MODE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
+__device__ __forceinline__ double strip_body(const Level& L, double sb, const double* __restrict__ src,
+                                             const double* __restrict__ bvec, double* __restrict__ out, double omega,
+                                             int Bp, int b, int c0w, int r0, int r1) {
+  const int W = L.W, nyp = L.ny + 1;
+  const i64 n = L.n;
+  const i64 Bv = SHARED ? 1 : Bp;
+  const i64 vb = SHARED ? 0 : b;
+  double s = 0.0;
+
+  // Column offsets of the window (q <-> grid column c0w - 1 + q) and of the strip (k <-> c0w + k),
+  // relative to column c0w.  Only the left halo of the first strip and the columns past the right
+  // edge (TAIL) are clamped; their window values are forced to 0.
+  int dq[RW + 2];
+  bool okq[RW + 2];
+#pragma unroll
+  for (int q = 0; q < RW + 2; ++q) {
+    int c = c0w - 1 + q;
+    okq[q] = c >= 0 && (!TAIL || c < W);
+    if (c < 0) c = 0;
+    if (TAIL && c > W - 1) c = W - 1;
+    dq[q] = c - c0w;
+  }
+  // D_k[i] lives at V[(k*n + i)*Bv + vb]; for k >= 1 a negative i (>= -n) still indexes valid,
+  // finite memory (the previous diagonal) and is only ever multiplied by a window value of 0.
+  const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
+  const double* __restrict__ p0 = L.v + vb + i0 * Bv;
+  const double* __restrict__ p1 = p0 + n * Bv;
+  const double* __restrict__ p2 = p1 + n * Bv;
+  const double* __restrict__ p3 = p2 + n * Bv;
+  const double* __restrict__ px = src + i0 * Bp + b;
+  const double* __restrict__ pb = bvec ? bvec + i0 * Bp + b : nullptr;
+  double* __restrict__ po = out ? out + i0 * Bp + b : nullptr;
+  const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
+
+  auto load_window = [&](const double* __restrict__ xrow, const double* __restrict__ d0row, double* dst) {
+#pragma unroll
+    for (int q = 0; q < RW + 2; ++q) {
+      double v = xrow[(i64)dq[q] * Bp];
+      if (XFROMB) v = omega * v / (sb * d0row[(i64)dq[q] * Bv]);
+      dst[q] = okq[q] ? v : 0.0;
+    }
+  };
+
+  double xm[RW + 2], xc[RW + 2], xp[RW + 2];
+  double n2p[RW], d3p[RW + 1];
+#pragma unroll
+  for (int q = 0; q < RW + 2; ++q) xm[q] = 0.0;
+  if (r0 > 0) load_window(px - rowX, p0 - rowV, xm);
+  load_window(px, p0, xc);
+#pragma unroll
+  for (int k = 0; k < RW; ++k) n2p[k] = (p2 - rowV)[(i64)dq[k + 1] * Bv];
+#pragma unroll
+  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (p3 - rowV)[(i64)dq[k + 1] * Bv] : 0.0;
+
+  for (int row = r0; row < r1; ++row) {
+    if (row + 1 < nyp) {
+      load_window(px + rowX, p0 + rowV, xp);
+    } else {
+#pragma unroll
+      for (int q = 0; q < RW + 2; ++q) xp[q] = 0.0;
+    }
+    double d0[RW], e1[RW + 1], n2c[RW], d3c[RW + 1];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      d0[k] = p0[(i64)dq[k + 1] * Bv];
+      n2c[k] = p2[(i64)dq[k + 1] * Bv];
+    }
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k) {
+      // east coupling of column c0w-1+k; column -1 reads the element before the row (valid
+      // memory, multiplied by a zero window value)
+      const int dc = TAIL ? dq[k] : k - 1;
+      e1[k] = p1[(i64)dc * Bv];
+      d3c[k] = (ND == 4) ? p3[(i64)dq[k + 1] * Bv] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int q = k + 1;
+      if (TAIL && c0w + k >= W) continue;
+      double acc = d0[k] * xc[q];
+      acc += e1[k + 1] * xc[q + 1] + e1[k] * xc[q - 1];
+      acc += n2c[k] * xp[q] + n2p[k] * xm[q];
+      if (ND == 4) acc += d3c[k] * xp[q - 1] + d3p[k + 1] * xm[q + 1];
+      const i64 o = (i64)k * Bp;
+      if (MODE == M_APPLY) {
+        const double y = sb * acc;
+        po[o] = y;
+        s += y * xc[q];
+      } else {
+        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega : pb[o];
+        const double res = bi - sb * acc;
+        if (MODE == M_RESID) {
+          if (po) po[o] = res;
+          s += res * res;
+        } else {
+          const double xo = xc[q] + omega * res / (sb * d0[k]);
+          po[o] = xo;
+          s += bi * xo;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RW + 2; ++q) {
+      xm[q] = xc[q];
+      xc[q] = xp[q];
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) n2p[k] = n2c[k];
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k) d3p[k] = d3c[k];
+    p0 += rowV; p1 += rowV; p2 += rowV; p3 += rowV;
+    px += rowX;
+    if (pb) pb += rowX;
+    if (po) po += rowX;
+  }
+  return s;
+}
+
+template <int MODE, int ND, bool SHARED, bool XFROMB, int RW>
+__global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
+                                                         const double* __restrict__ xin,
+                                                         const double* __restrict__ bvec, double* __restrict__ out,
+                                                         double omega, double* __restrict__ part, int Bp, int ncb,
+                                                         int TR) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y * kWave + lane;
+  const int rc = blockIdx.x / ncb, cb = blockIdx.x - rc * ncb;
+  const int c0w = (cb * 4 + wave) * RW;
+  const int r0 = rc * TR;
+  const int nyp = L.ny + 1;
+  const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+  const double sb = scale ? scale[b] : 1.0;
+  const double* __restrict__ src = XFROMB ? bvec : xin;
+  double s = 0.0;
+  if (c0w < L.W && r0 < r1) {
+    if (c0w + RW + 1 > L.W)
+      s = strip_body<MODE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, Bp, b, c0w, r0, r1);
+    else
+      s = strip_body<MODE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, Bp, b, c0w, r0, r1);
+  }
+  if (part) {
+    const double t = block_sum_per_sample(s, Bp, lds);
+    if (wave == 0) part[(i64)blockIdx.x * Bp + b] = t;
+  }
+}
+
+constexpr int kStripCols = 8;
+constexpr int kPartBlocks = 2048;  // capacity (in blocks) of every partial-sum buffer
+
+struct StripGeom {
+  bool use;
+  int ncb, nrc, TR;
+};
+
+inline StripGeom strip_geom(const Level& L, int Bp) {
+  StripGeom g{false, 0, 0, 0};
+  if (Bp < kWave || L.W < 4 * kStripCols || L.ny + 1 < 16) return g;
+  g.use = true;
+  g.ncb = (L.W + 4 * kStripCols - 1) / (4 * kStripCols);
+  const int gy = Bp / kWave;
+  static const int target = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
+  int nrc = (target + g.ncb * gy - 1) / (g.ncb * gy);
+  const int nyp = L.ny + 1;
+  if (nrc > nyp / 8) nrc = nyp / 8;
+  if (nrc < 1) nrc = 1;
+  while (g.ncb * nrc > kPartBlocks) --nrc;
+  g.TR = (nyp + nrc - 1) / nrc;
+  g.nrc = (nyp + g.TR - 1) / g.TR;
+  return g;
+}
+
+template <int MODE, bool XFROMB>
+void launch_strip(const Level& L, int Bv, const double* scale, const double* xin, const double* bvec, double* out,
+                  double omega, double* part, int Bp, const StripGeom& g, hipStream_t st) {
+  dim3 grid(g.ncb * g.nrc, Bp / kWave);
+#define STRIP(ND_, SH_)                                                                                          \
+  hipLaunchKernelGGL((dia_strip_kernel<MODE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, scale, xin, \
+                     bvec, out, omega, part, Bp, g.ncb, g.TR)
+  if (L.nd == 3) {
+    if (Bv == 1) STRIP(3, true); else STRIP(3, false);
+  } else {
+    if (Bv == 1) STRIP(4, true); else STRIP(4, false);
+  }
+#undef STRIP
 }
 
 // coarse rhs = P^T r (P = P1 interpolation on the nested triangulation), 0 on coarse Dirichlet rows
@@ -303,45 +510,106 @@ inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
 
 #define LAUNCH(kernel, n, ...) hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__)
 
+// ---- operator dispatch: strip kernels on big levels, simple kernels on small ones ----------------
+// Each returns the number of partial blocks it wrote (when `part` != NULL).
+int op_jacobi(const Hier& H, int l, const double* rhs, const double* xin, double* xout, double* part,
+              hipStream_t st) {
+  const Level& L = H.lev[l];
+  const StripGeom g = strip_geom(L, H.Bp);
+  if (g.use && xin) {
+    launch_strip<M_JACOBI, false>(L, H.Bv, H.scale, xin, rhs, xout, H.omega, part, H.Bp, g, st);
+    return g.ncb * g.nrc;
+  }
+  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, xin, xout, H.omega, part, H.Bp);
+  return lgrid(L.n, H.Bp).x;
+}
+
+// two sweeps from a zero guess in one pass over rhs: x1 = w D^-1 rhs is formed on the fly
+int op_jacobi_first2(const Hier& H, int l, const double* rhs, double* xa, double* xb, double* part, double** result,
+                     hipStream_t st) {
+  const Level& L = H.lev[l];
+  const StripGeom g = strip_geom(L, H.Bp);
+  if (g.use) {
+    launch_strip<M_JACOBI, true>(L, H.Bv, H.scale, (const double*)nullptr, rhs, xa, H.omega, part, H.Bp, g, st);
+    *result = xa;
+    return g.ncb * g.nrc;
+  }
+  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, (const double*)nullptr, xa, H.omega, (double*)nullptr, H.Bp);
+  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, (const double*)xa, xb, H.omega, part, H.Bp);
+  *result = xb;
+  return lgrid(L.n, H.Bp).x;
+}
+
+int op_residual(const Hier& H, int l, const double* rhs, const double* x, double* res, double* part, hipStream_t st) {
+  const Level& L = H.lev[l];
+  const StripGeom g = strip_geom(L, H.Bp);
+  if (g.use) {
+    launch_strip<M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, part, H.Bp, g, st);
+    return g.ncb * g.nrc;
+  }
+  LAUNCH(dia_residual_kernel, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
+  return lgrid(L.n, H.Bp).x;
+}
+
+int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStream_t st) {
+  const Level& L = H.lev[0];
+  const StripGeom g = strip_geom(L, H.Bp);
+  if (g.use) {
+    launch_strip<M_APPLY, false>(L, H.Bv, H.scale, x, (const double*)nullptr, y, 0.0, part, H.Bp, g, st);
+    return g.ncb * g.nrc;
+  }
+  LAUNCH(dia_apply_dot_kernel, L.n, L, H.Bv, H.scale, x, y, part, H.Bp);
+  return lgrid(L.n, H.Bp).x;
+}
+
 // z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
-// fine sweep also leaves the partials of rhs0.z there.
-double* vcycle(const Hier& H, const double* rhs0, double* rz_part, hipStream_t st) {
+// fine sweep also leaves the partials of rhs0.z there (*rz_blocks of them).
+double* vcycle(const Hier& H, const double* rhs0, double* rz_part, int* rz_blocks, hipStream_t st) {
   const double* rhs[kMaxLevels];
   double* cur[kMaxLevels];
   rhs[0] = rhs0;
   const int last = H.nl - 1;
-  // downward leg
-  for (int l = 0; l <= last; ++l) {
+  for (int l = 0; l <= last; ++l) {  // downward leg
     const Level& L = H.lev[l];
+    const int sweeps = (l == last) ? H.n_coarse : H.nu;
+    const bool only = (H.nl == 1);  // no coarse level: the cycle is `sweeps` Jacobi sweeps
     double* a = H.xa[l];
     double* b2 = H.xb[l];
-    const int sweeps = (l == last) ? H.n_coarse : H.nu;
-    const bool only = (H.nl == 1);  // no coarse level: the V-cycle is `sweeps` Jacobi sweeps
-    LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)nullptr, a, H.omega,
-           (only && sweeps == 1) ? rz_part : (double*)nullptr, H.Bp);
-    for (int s = 1; s < sweeps; ++s) {
-      LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, b2, H.omega,
-             (only && s == sweeps - 1) ? rz_part : (double*)nullptr, H.Bp);
+    int done;
+    if (sweeps >= 2) {
+      double* resu;
+      const int nb = op_jacobi_first2(H, l, rhs[l], a, b2, (only && sweeps == 2) ? rz_part : nullptr, &resu, st);
+      if (only && sweeps == 2 && rz_blocks) *rz_blocks = nb;
+      if (resu != a) { double* t = a; a = b2; b2 = t; }
+      done = 2;
+    } else {
+      const int nb = op_jacobi(H, l, rhs[l], nullptr, a, (only && sweeps == 1) ? rz_part : nullptr, st);
+      if (only && sweeps == 1 && rz_blocks) *rz_blocks = nb;
+      done = 1;
+    }
+    for (int s = done; s < sweeps; ++s) {
+      const int nb = op_jacobi(H, l, rhs[l], a, b2, (only && s == sweeps - 1) ? rz_part : nullptr, st);
+      if (only && s == sweeps - 1 && rz_blocks) *rz_blocks = nb;
       double* t = a; a = b2; b2 = t;
     }
     cur[l] = a;
     if (l < last) {
-      LAUNCH(dia_residual_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, H.res[l], (double*)nullptr, H.Bp);
+      op_residual(H, l, rhs[l], a, H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
       LAUNCH(mg_restrict_kernel, C.n, L, C, (const double*)H.res[l], H.rhs[l + 1], H.Bp);
       rhs[l + 1] = H.rhs[l + 1];
     }
   }
-  // upward leg
-  for (int l = last - 1; l >= 0; --l) {
+  for (int l = last - 1; l >= 0; --l) {  // upward leg
     const Level& L = H.lev[l];
     const Level& C = H.lev[l + 1];
     double* a = cur[l];
     double* b2 = (a == H.xa[l]) ? H.xb[l] : H.xa[l];
     LAUNCH(mg_prolong_add_kernel, L.n, L, C, (const double*)cur[l + 1], a, H.Bp);
     for (int s = 0; s < H.nu; ++s) {
-      LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs[l], (const double*)a, b2, H.omega,
-             (l == 0 && s == H.nu - 1) ? rz_part : (double*)nullptr, H.Bp);
+      const bool lastsweep = (l == 0 && s == H.nu - 1);
+      const int nb = op_jacobi(H, l, rhs[l], a, b2, lastsweep ? rz_part : nullptr, st);
+      if (lastsweep && rz_blocks) *rz_blocks = nb;
       double* t = a; a = b2; b2 = t;
     }
     cur[l] = a;
@@ -391,7 +659,8 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
   if (fill_hier(H, levels, n_levels, 1, Bp, nullptr, 0.8, 1, 1)) return -1;
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = lgrid(H.lev[0].n, Bp).x;
-  return carve(H, nullptr) + 3 * nb + 2 * nblk * Bp + 16LL * Bp + 64;
+  (void)nblk;
+  return carve(H, nullptr) + 3 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
@@ -412,45 +681,46 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   double* p = r + nb;
   double* Ap = p + nb;
   double* partA = Ap + nb;
-  double* partB = partA + (long long)nblk * Bp;
-  double* sc = partB + (long long)nblk * Bp;
+  double* partB = partA + (long long)kPartBlocks * Bp;
+  double* sc = partB + (long long)kPartBlocks * Bp;
   PcgScalars S;
   S.rz = sc; S.alpha = sc + Bp; S.beta = sc + 2 * Bp; S.bb = sc + 3 * Bp; S.tol2 = sc + 4 * Bp;
   S.active = (int*)(sc + 5 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 6 * Bp);
   const dim3 sgrid((Bp + 63) / 64);
-#define SCALAR(phase, part) \
-  hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), nblk, Bp, tol, S, relres)
+#define SCALAR(phase, part, nb_) \
+  hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
 
+  int nbz = 0, nba = 0;
   LAUNCH(pcg_init_kernel, n, b, x, r, partA, n, Bp);
-  SCALAR(S_INIT, partA);
-  double* z = vcycle(H, r, partB, st);
-  SCALAR(S_RZ0, partB);
+  SCALAR(S_INIT, partA, nblk);
+  double* z = vcycle(H, r, partB, &nbz, st);
+  SCALAR(S_RZ0, partB, nbz);
   LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 1, n, Bp);
   rc = diffhe::check_launch();
   if (rc) return rc;
 
   int it = 0, n_active = -1;
   while (it < max_iter) {
-    LAUNCH(dia_apply_dot_kernel, n, L0, Bv, scale, (const double*)p, Ap, partA, Bp);
-    SCALAR(S_ALPHA, partA);
+    nba = op_apply_dot(H, p, Ap, partA, st);
+    SCALAR(S_ALPHA, partA, nba);
     LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, x, r, partA, n, Bp);
-    SCALAR(S_CONV, partA);
+    SCALAR(S_CONV, partA, nblk);
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
     if (rc) return rc;
     // overlap the convergence read-back with the next V-cycle: enqueue it first, then wait
-    z = vcycle(H, r, partB, st);
-    SCALAR(S_BETA, partB);
+    z = vcycle(H, r, partB, &nbz, st);
+    SCALAR(S_BETA, partB, nbz);
     LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 0, n, Bp);
     rc = diffhe::check(hipStreamSynchronize(st));
     if (rc) return rc;
     n_active = status_host[2];
     if (n_active == 0) break;
   }
-  LAUNCH(dia_residual_kernel, n, L0, Bv, scale, b, (const double*)x, (double*)nullptr, partA, Bp);
-  SCALAR(S_RELRES, partA);
+  nba = op_residual(H, 0, b, x, nullptr, partA, st);
+  SCALAR(S_RELRES, partA, nba);
   rc = diffhe::check_launch();
   if (rc) return rc;
   status_host[0] = it;
@@ -458,7 +728,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   return DIFFHE_OK;
 }
 
-extern "C" int diffhe_lattice_blocks(int n, int Bp) { return (int)lgrid(n, Bp).x; }
+extern "C" int diffhe_lattice_blocks(int n, int Bp) { (void)n; (void)Bp; return kPartBlocks; }
 
 extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
                                     double* y, double* part, int Bp, void* stream) {
@@ -466,8 +736,7 @@ extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const 
   Hier H;
   int rc = fill_hier(H, level, 1, Bv, Bp, scale, 0.8, 1, 1);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  LAUNCH(dia_apply_dot_kernel, H.lev[0].n, H.lev[0], Bv, scale, x, y, part, Bp);
+  op_apply_dot(H, x, y, part, (hipStream_t)stream);
   return diffhe::check_launch();
 }
 
@@ -477,8 +746,7 @@ extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const
   Hier H;
   int rc = fill_hier(H, level, 1, Bv, Bp, scale, omega, 1, 1);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  LAUNCH(dia_jacobi_kernel, H.lev[0].n, H.lev[0], Bv, scale, rhs, xin, xout, omega, (double*)nullptr, Bp);
+  op_jacobi(H, 0, rhs, xin, xout, nullptr, (hipStream_t)stream);
   return diffhe::check_launch();
 }
 

@@ -354,3 +354,76 @@ def test_2d_64_batch_vs_oracle(method):
         uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, float(kap[b]), f[b].numpy(), lambda u: 2 * u)
         assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
         assert abs(float(kt.grad[b]) - dko.sum()) <= RTOL_GRAD * abs(dko.sum())
+
+
+@pytest.mark.parametrize("graded", [False, True])
+def test_lattice_strip_kernels_batch64(graded):
+    """Batch >= 64 and a grid >= 32 rows: the register-window strip kernels are the ones that
+    run (fine level) -- per-sample scalar kappa (shared matrix + scale) and per-sample
+    per-element kappa (matrix per sample), right-angled (3 diagonals) and skewed (4)."""
+    nx, ny = 40, 48
+    base = FEMesh.rectangle(nx, ny, (0.0, 1.0), (0.0, 1.5), 0.2)
+    rng = np.random.default_rng(21)
+    xy = base.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
+    if graded:
+        xy[1:-1, 1:-1] += rng.uniform(-0.2, 0.2, (ny - 1, nx - 1, 2)) * np.array([1.0 / nx, 1.5 / ny])
+    mesh = FEMesh(nodes=torch.from_numpy(xy.reshape(-1, 2)), elements=base.elements,
+                  dirichlet_nodes=dict(base.dirichlet_nodes))
+    nodes, el, bn, bv = arrays(mesh)
+    B = 64
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    for kap in (rng.uniform(0.5, 2.0, B), np.exp(0.4 * rng.standard_normal((B, mesh.n_elements)))):
+        kt = torch.from_numpy(kap).requires_grad_(True)
+        ft = torch.from_numpy(f).requires_grad_(True)
+        solver = DifferentiableFESolver(mesh, kt)
+        u = solver(ft)
+        assert solver.last_info.path == "lattice-mgpcg"
+        (u ** 2).sum().backward()
+        for b in (0, 31, 63):
+            uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
+            assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+            got = kt.grad[b].numpy()
+            assert rel_err(got, dko if kap.ndim == 2 else dko.sum()) < RTOL_GRAD
+            assert rel_err(ft.grad[b].numpy(), dfo) < RTOL_GRAD
+
+
+def test_lattice_operator_kernels_vs_dense():
+    """diffhe_lattice_apply / diffhe_lattice_smooth (strip and simple variants) against the
+    oracle's dense K with identity Dirichlet rows."""
+    from diffhe.solver import _Engine, K_SAMPLE_ELEM
+    from diffhe.plan import padded_batch
+    nx, ny = 20, 36
+    mesh = FEMesh.rectangle(nx, ny, (0.0, 1.0), (0.0, 2.0), 0.0)
+    nodes, el, bn, bv = arrays(mesh)
+    n, m = mesh.n_nodes, mesh.n_elements
+    dev = torch.device("cuda", 0)
+    plan = get_plan(mesh, dev)
+    rng = np.random.default_rng(8)
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for B in (4, 64):
+        kap = np.exp(0.3 * rng.standard_normal((B, m)))
+        eng = _Engine(plan, 1e-12, 100, 1, "gather")
+        Bp = padded_batch(B)
+        vals, Bv, scale, lift, _ = eng.lattice_assemble(torch.from_numpy(kap), K_SAMPLE_ELEM, B, Bp)
+        arr = eng.lattice_levels(vals)
+        x = rng.standard_normal((n, Bp))
+        x[bn] = 0.0
+        rhs = rng.standard_normal((n, Bp))
+        rhs[bn] = 0.0
+        xd, rd = torch.from_numpy(x).to(dev), torch.from_numpy(rhs).to(dev)
+        y = torch.empty_like(xd)
+        xo = torch.empty_like(xd)
+        part = torch.empty(L.diffhe_lattice_blocks(n, Bp) * Bp, dtype=T64, device=dev)
+        _hip.check(L.diffhe_lattice_apply(arr, Bv, None, _hip.ptr(xd), _hip.ptr(y), _hip.ptr(part), Bp, st), "apply")
+        _hip.check(L.diffhe_lattice_smooth(arr, Bv, None, _hip.ptr(rd), _hip.ptr(xd), _hip.ptr(xo), 0.8, Bp, st),
+                   "smooth")
+        for b in (0, B - 1):
+            K, _ = orc.assemble_dense(nodes, el, kap[b], np.zeros(n))
+            K[bn, :] = 0.0
+            K[:, bn] = 0.0
+            K[bn, bn] = 1.0
+            yref = K @ x[:, b]
+            assert rel_err(y[:, b].cpu().numpy(), yref) < 1e-13
+            xref = x[:, b] + 0.8 * (rhs[:, b] - yref) / np.diag(K)
+            assert rel_err(xo[:, b].cpu().numpy(), xref) < 1e-13
