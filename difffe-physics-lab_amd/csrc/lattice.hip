@@ -30,15 +30,16 @@ struct Level {
 __device__ inline int dia_off(const Level& L, int k) { return k == 1 ? 1 : (k == 2 ? L.W : L.nx); }
 
 // sum_j K[i,j] x[j] for sample b (unscaled)
-__device__ inline double dia_row(const Level& L, int Bv, int vb, const double* __restrict__ x, int i, int b, int Bp) {
+template <typename TV>
+__device__ inline double dia_row(const Level& L, int Bv, int vb, const TV* __restrict__ x, int i, int b, int Bp) {
   const i64 n = L.n;
-  double acc = L.v[(i64)i * Bv + vb] * x[(i64)i * Bp + b];
+  double acc = L.v[(i64)i * Bv + vb] * (double)x[(i64)i * Bp + b];
 #pragma unroll
   for (int k = 1; k < 4; ++k) {
     if (k < L.nd) {
       const int off = dia_off(L, k);
-      if (i + off < L.n) acc += L.v[((i64)k * n + i) * Bv + vb] * x[(i64)(i + off) * Bp + b];
-      if (i - off >= 0) acc += L.v[((i64)k * n + (i - off)) * Bv + vb] * x[(i64)(i - off) * Bp + b];
+      if (i + off < L.n) acc += L.v[((i64)k * n + i) * Bv + vb] * (double)x[(i64)(i + off) * Bp + b];
+      if (i - off >= 0) acc += L.v[((i64)k * n + (i - off)) * Bv + vb] * (double)x[(i64)(i - off) * Bp + b];
     }
   }
   return acc;
@@ -73,18 +74,18 @@ __global__ __launch_bounds__(256) void dia_apply_dot_kernel(Level L, int Bv, con
 }
 
 // r = b - A x ; optional part = per-sample partial of r.r
+template <typename TV>
 __global__ __launch_bounds__(256) void dia_residual_kernel(Level L, int Bv, const double* __restrict__ scale,
-                                                            const double* __restrict__ bvec,
-                                                            const double* __restrict__ x, double* __restrict__ r,
-                                                            double* __restrict__ part, int Bp) {
+                                                            const TV* __restrict__ bvec, const TV* __restrict__ x,
+                                                            TV* __restrict__ r, double* __restrict__ part, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double ri = bvec[o] - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
-    if (r) r[o] = ri;
+    const double ri = (double)bvec[o] - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
+    if (r) r[o] = (TV)ri;
     s += ri * ri;
   }
   if (part) STORE_PARTIAL(part, s);
@@ -92,10 +93,11 @@ __global__ __launch_bounds__(256) void dia_residual_kernel(Level L, int Bv, cons
 
 // damped Jacobi: xout = xin + omega (b - A xin) / D   (xin == NULL: xin = 0)
 // optional part = per-sample partial of b.xout  (the r.z dot of the CG, fused into the last sweep)
+template <typename TV>
 __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const double* __restrict__ scale,
-                                                          const double* __restrict__ bvec,
-                                                          const double* __restrict__ xin, double* __restrict__ xout,
-                                                          double omega, double* __restrict__ part, int Bp) {
+                                                          const TV* __restrict__ bvec, const TV* __restrict__ xin,
+                                                          TV* __restrict__ xout, double omega,
+                                                          double* __restrict__ part, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const int vb = Bv == 1 ? 0 : nm.b;
@@ -104,13 +106,13 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
     const i64 o = (i64)i * Bp + nm.b;
     const double sc = row_scale(L, scale, i, nm.b);
     const double d = sc * L.v[(i64)i * Bv + vb];
-    const double bi = bvec[o];
+    const double bi = (double)bvec[o];
     double xo;
     if (xin)
-      xo = xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) / d;
+      xo = (double)xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) / d;
     else
       xo = omega * bi / d;
-    xout[o] = xo;
+    xout[o] = (TV)xo;
     s += bi * xo;
   }
   if (part) STORE_PARTIAL(part, s);
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
 // ---------------------------------------------------------------------------------------------
 enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
 
-template <int MODE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
-__device__ __forceinline__ double strip_body(const Level& L, double sb, const double* __restrict__ src,
-                                             const double* __restrict__ bvec, double* __restrict__ out, double omega,
-                                             int Bp, int b, int c0w, int r0, int r1) {
+template <typename TV, int MODE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
+__device__ __forceinline__ double strip_body(const Level& L, double sb, const TV* __restrict__ src,
+                                             const TV* __restrict__ bvec, TV* __restrict__ out, double omega,
+                                             double omega_in, int Bp, int b, int c0w, int r0, int r1) {
   const int W = L.W, nyp = L.ny + 1;
   const i64 n = L.n;
   const i64 Bv = SHARED ? 1 : Bp;
@@ -162,16 +164,16 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const do
   const double* __restrict__ p1 = p0 + n * Bv;
   const double* __restrict__ p2 = p1 + n * Bv;
   const double* __restrict__ p3 = p2 + n * Bv;
-  const double* __restrict__ px = src + i0 * Bp + b;
-  const double* __restrict__ pb = bvec ? bvec + i0 * Bp + b : nullptr;
-  double* __restrict__ po = out ? out + i0 * Bp + b : nullptr;
+  const TV* __restrict__ px = src + i0 * Bp + b;
+  const TV* __restrict__ pb = bvec ? bvec + i0 * Bp + b : nullptr;
+  TV* __restrict__ po = out ? out + i0 * Bp + b : nullptr;
   const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
 
-  auto load_window = [&](const double* __restrict__ xrow, const double* __restrict__ d0row, double* dst) {
+  auto load_window = [&](const TV* __restrict__ xrow, const double* __restrict__ d0row, double* dst) {
 #pragma unroll
     for (int q = 0; q < RW + 2; ++q) {
-      double v = xrow[(i64)dq[q] * Bp];
-      if (XFROMB) v = omega * v / (sb * d0row[(i64)dq[q] * Bv]);
+      double v = (double)xrow[(i64)dq[q] * Bp];
+      if (XFROMB) v = omega_in * v / (sb * d0row[(i64)dq[q] * Bv]);
       dst[q] = okq[q] ? v : 0.0;
     }
   };
@@ -219,17 +221,17 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const do
       const i64 o = (i64)k * Bp;
       if (MODE == M_APPLY) {
         const double y = sb * acc;
-        po[o] = y;
+        po[o] = (TV)y;
         s += y * xc[q];
       } else {
-        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega : pb[o];
+        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega_in : (double)pb[o];
         const double res = bi - sb * acc;
         if (MODE == M_RESID) {
-          if (po) po[o] = res;
+          if (po) po[o] = (TV)res;
           s += res * res;
         } else {
           const double xo = xc[q] + omega * res / (sb * d0[k]);
-          po[o] = xo;
+          po[o] = (TV)xo;
           s += bi * xo;
         }
       }
@@ -251,12 +253,12 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const do
   return s;
 }
 
-template <int MODE, int ND, bool SHARED, bool XFROMB, int RW>
+template <typename TV, int MODE, int ND, bool SHARED, bool XFROMB, int RW>
 __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
-                                                         const double* __restrict__ xin,
-                                                         const double* __restrict__ bvec, double* __restrict__ out,
-                                                         double omega, double* __restrict__ part, int Bp, int ncb,
-                                                         int TR) {
+                                                         const TV* __restrict__ xin, const TV* __restrict__ bvec,
+                                                         TV* __restrict__ out,
+                                                         double omega, double omega_in, double* __restrict__ part,
+                                                         int Bp, int ncb, int TR) {
   __shared__ double lds[4 * kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -267,13 +269,13 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
   const int nyp = L.ny + 1;
   const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
   const double sb = scale ? scale[b] : 1.0;
-  const double* __restrict__ src = XFROMB ? bvec : xin;
+  const TV* __restrict__ src = XFROMB ? bvec : xin;
   double s = 0.0;
   if (c0w < L.W && r0 < r1) {
     if (c0w + RW + 1 > L.W)
-      s = strip_body<MODE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, Bp, b, c0w, r0, r1);
+      s = strip_body<TV, MODE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, Bp, b, c0w, r0, r1);
     else
-      s = strip_body<MODE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, Bp, b, c0w, r0, r1);
+      s = strip_body<TV, MODE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, Bp, b, c0w, r0, r1);
   }
   if (part) {
     const double t = block_sum_per_sample(s, Bp, lds);
@@ -306,13 +308,13 @@ inline StripGeom strip_geom(const Level& L, int Bp) {
   return g;
 }
 
-template <int MODE, bool XFROMB>
-void launch_strip(const Level& L, int Bv, const double* scale, const double* xin, const double* bvec, double* out,
-                  double omega, double* part, int Bp, const StripGeom& g, hipStream_t st) {
+template <typename TV, int MODE, bool XFROMB>
+void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, const TV* bvec, TV* out,
+                  double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st) {
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
 #define STRIP(ND_, SH_)                                                                                          \
-  hipLaunchKernelGGL((dia_strip_kernel<MODE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, scale, xin, \
-                     bvec, out, omega, part, Bp, g.ncb, g.TR)
+  hipLaunchKernelGGL((dia_strip_kernel<TV, MODE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, scale, xin, \
+                     bvec, out, omega, omega_in, part, Bp, g.ncb, g.TR)
   if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true); else STRIP(3, false);
   } else {
@@ -322,8 +324,9 @@ void launch_strip(const Level& L, int Bv, const double* scale, const double* xin
 }
 
 // coarse rhs = P^T r (P = P1 interpolation on the nested triangulation), 0 on coarse Dirichlet rows
-__global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, const double* __restrict__ r,
-                                                           double* __restrict__ rc, int Bp) {
+template <typename TV>
+__global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, const TV* __restrict__ r,
+                                                           TV* __restrict__ rc, int Bp) {
   const NodeMap nm = node_map(Bp);
   for (int I = nm.node0; I < C.n; I += nm.stride) {
     double out = 0.0;
@@ -332,21 +335,22 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, cons
       const int fi = 2 * ci, fj = 2 * cj;
       const i64 c = (i64)fi * F.W + fj;
       double h = 0.0;
-      if (fj > 0) h += r[(c - 1) * Bp + nm.b];
-      if (fj < F.nx) h += r[(c + 1) * Bp + nm.b];
-      if (fi > 0) h += r[(c - F.W) * Bp + nm.b];
-      if (fi < F.ny) h += r[(c + F.W) * Bp + nm.b];
-      if (fi > 0 && fj < F.nx) h += r[(c - F.W + 1) * Bp + nm.b];
-      if (fi < F.ny && fj > 0) h += r[(c + F.W - 1) * Bp + nm.b];
-      out = r[c * Bp + nm.b] + 0.5 * h;
+      if (fj > 0) h += (double)r[(c - 1) * Bp + nm.b];
+      if (fj < F.nx) h += (double)r[(c + 1) * Bp + nm.b];
+      if (fi > 0) h += (double)r[(c - F.W) * Bp + nm.b];
+      if (fi < F.ny) h += (double)r[(c + F.W) * Bp + nm.b];
+      if (fi > 0 && fj < F.nx) h += (double)r[(c - F.W + 1) * Bp + nm.b];
+      if (fi < F.ny && fj > 0) h += (double)r[(c + F.W - 1) * Bp + nm.b];
+      out = (double)r[c * Bp + nm.b] + 0.5 * h;
     }
-    rc[(i64)I * Bp + nm.b] = out;
+    rc[(i64)I * Bp + nm.b] = (TV)out;
   }
 }
 
 // x += P e  (0 on fine Dirichlet rows)
-__global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, const double* __restrict__ e,
-                                                              double* __restrict__ x, int Bp) {
+template <typename TV>
+__global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, const TV* __restrict__ e,
+                                                              TV* __restrict__ x, int Bp) {
   const NodeMap nm = node_map(Bp);
   for (int i = nm.node0; i < F.n; i += nm.stride) {
     if (F.bc[i]) continue;
@@ -355,14 +359,14 @@ __global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, c
     const i64 c = (i64)ci * C.W + cj;
     double v;
     if (!(fi & 1) && !(fj & 1))
-      v = e[c * Bp + nm.b];
+      v = (double)e[c * Bp + nm.b];
     else if (!(fi & 1))
-      v = 0.5 * (e[c * Bp + nm.b] + e[(c + 1) * Bp + nm.b]);
+      v = 0.5 * ((double)e[c * Bp + nm.b] + (double)e[(c + 1) * Bp + nm.b]);
     else if (!(fj & 1))
-      v = 0.5 * (e[c * Bp + nm.b] + e[(c + C.W) * Bp + nm.b]);
-    else
-      v = 0.5 * (e[(c + 1) * Bp + nm.b] + e[(c + C.W) * Bp + nm.b]);  // midpoint of the quad diagonal b-d
-    x[(i64)i * Bp + nm.b] += v;
+      v = 0.5 * ((double)e[c * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
+    else  // midpoint of the quad diagonal b-d
+      v = 0.5 * ((double)e[(c + 1) * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
+    x[(i64)i * Bp + nm.b] = (TV)((double)x[(i64)i * Bp + nm.b] + v);
   }
 }
 
@@ -388,8 +392,8 @@ __global__ __launch_bounds__(256) void mg_restrict_kappa_kernel(const double* __
 
 // ---- CG vector kernels ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
-                                                        double* __restrict__ r, double* __restrict__ part, int n,
-                                                        int Bp) {
+                                                        double* __restrict__ r, float* __restrict__ r32,
+                                                        double* __restrict__ part, int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   double s = 0.0;
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict_
     const double bi = bvec[o];
     x[o] = 0.0;
     r[o] = bi;
+    if (r32) r32[o] = (float)bi;
     s += bi * bi;
   }
   STORE_PARTIAL(part, s);
@@ -405,8 +410,8 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict_
 
 __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                           const double* __restrict__ alpha, double* __restrict__ x,
-                                                          double* __restrict__ r, double* __restrict__ part, int n,
-                                                          int Bp) {
+                                                          double* __restrict__ r, float* __restrict__ r32,
+                                                          double* __restrict__ part, int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double a = alpha[nm.b];
@@ -416,19 +421,21 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
     x[o] += a * p[o];
     const double ri = r[o] - a * Ap[o];
     r[o] = ri;
+    if (r32) r32[o] = (float)ri;
     s += ri * ri;
   }
   STORE_PARTIAL(part, s);
 }
 
 // p = z + beta p   (first: p = z)
-__global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restrict__ z, const double* __restrict__ beta,
+template <typename TV>
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(const TV* __restrict__ z, const double* __restrict__ beta,
                                                             double* __restrict__ p, int first, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   const double be = first ? 0.0 : beta[nm.b];
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    p[o] = first ? z[o] : z[o] + be * p[o];
+    p[o] = first ? (double)z[o] : (double)z[o] + be * p[o];
   }
 }
 
@@ -500,10 +507,10 @@ struct Hier {
   Level lev[kMaxLevels];
   int nl, Bv, Bp;
   const double* scale;
-  double omega;
+  double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
   int nu, n_coarse;
   // per-level work vectors
-  double *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];
+  void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
 };
 
 inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
@@ -511,43 +518,48 @@ inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
 #define LAUNCH(kernel, n, ...) hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__)
 
 // ---- operator dispatch: strip kernels on big levels, simple kernels on small ones ----------------
-// Each returns the number of partial blocks it wrote (when `part` != NULL).
-int op_jacobi(const Hier& H, int l, const double* rhs, const double* xin, double* xout, double* part,
+// Each returns the number of partial blocks it wrote (when `part` != NULL).  TV is the storage
+// type of the vectors (double, or float inside a single-precision preconditioner); arithmetic is
+// always fp64 in registers.
+template <typename TV>
+int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, double omega, double* part,
               hipStream_t st) {
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp);
   if (g.use && xin) {
-    launch_strip<M_JACOBI, false>(L, H.Bv, H.scale, xin, rhs, xout, H.omega, part, H.Bp, g, st);
+    launch_strip<TV, M_JACOBI, false>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part, H.Bp, g, st);
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, xin, xout, H.omega, part, H.Bp);
+  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, xin, xout, omega, part, H.Bp);
   return lgrid(L.n, H.Bp).x;
 }
 
-// two sweeps from a zero guess in one pass over rhs: x1 = w D^-1 rhs is formed on the fly
-int op_jacobi_first2(const Hier& H, int l, const double* rhs, double* xa, double* xb, double* part, double** result,
-                     hipStream_t st) {
+// two sweeps from a zero guess in one pass over rhs: x1 = w0 D^-1 rhs is formed on the fly
+template <typename TV>
+int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double w0, double w1, double* part,
+                     TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp);
   if (g.use) {
-    launch_strip<M_JACOBI, true>(L, H.Bv, H.scale, (const double*)nullptr, rhs, xa, H.omega, part, H.Bp, g, st);
+    launch_strip<TV, M_JACOBI, true>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0, part, H.Bp, g, st);
     *result = xa;
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, (const double*)nullptr, xa, H.omega, (double*)nullptr, H.Bp);
-  LAUNCH(dia_jacobi_kernel, L.n, L, H.Bv, H.scale, rhs, (const double*)xa, xb, H.omega, part, H.Bp);
+  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, xa, w0, (double*)nullptr, H.Bp);
+  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, xb, w1, part, H.Bp);
   *result = xb;
   return lgrid(L.n, H.Bp).x;
 }
 
-int op_residual(const Hier& H, int l, const double* rhs, const double* x, double* res, double* part, hipStream_t st) {
+template <typename TV>
+int op_residual(const Hier& H, int l, const TV* rhs, const TV* x, TV* res, double* part, hipStream_t st) {
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp);
   if (g.use) {
-    launch_strip<M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, part, H.Bp, g, st);
+    launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st);
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_residual_kernel, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
+  LAUNCH(dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
   return lgrid(L.n, H.Bp).x;
 }
 
@@ -555,7 +567,7 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
   const Level& L = H.lev[0];
   const StripGeom g = strip_geom(L, H.Bp);
   if (g.use) {
-    launch_strip<M_APPLY, false>(L, H.Bv, H.scale, x, (const double*)nullptr, y, 0.0, part, H.Bp, g, st);
+    launch_strip<double, M_APPLY, false>(L, H.Bv, H.scale, x, (const double*)nullptr, y, 0.0, 0.0, part, H.Bp, g, st);
     return g.ncb * g.nrc;
   }
   LAUNCH(dia_apply_dot_kernel, L.n, L, H.Bv, H.scale, x, y, part, H.Bp);
@@ -564,53 +576,56 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
 
 // z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
 // fine sweep also leaves the partials of rhs0.z there (*rz_blocks of them).
-double* vcycle(const Hier& H, const double* rhs0, double* rz_part, int* rz_blocks, hipStream_t st) {
-  const double* rhs[kMaxLevels];
-  double* cur[kMaxLevels];
+template <typename TV>
+TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st) {
+  const TV* rhs[kMaxLevels];
+  TV* cur[kMaxLevels];
   rhs[0] = rhs0;
   const int last = H.nl - 1;
   for (int l = 0; l <= last; ++l) {  // downward leg
     const Level& L = H.lev[l];
     const int sweeps = (l == last) ? H.n_coarse : H.nu;
     const bool only = (H.nl == 1);  // no coarse level: the cycle is `sweeps` Jacobi sweeps
-    double* a = H.xa[l];
-    double* b2 = H.xb[l];
+    TV* a = (TV*)H.xa[l];
+    TV* b2 = (TV*)H.xb[l];
     int done;
     if (sweeps >= 2) {
-      double* resu;
-      const int nb = op_jacobi_first2(H, l, rhs[l], a, b2, (only && sweeps == 2) ? rz_part : nullptr, &resu, st);
+      TV* resu;
+      const int nb = op_jacobi_first2<TV>(H, l, rhs[l], a, b2, H.omega[0], H.omega[1 % H.nu],
+                                          (only && sweeps == 2) ? rz_part : nullptr, &resu, st);
       if (only && sweeps == 2 && rz_blocks) *rz_blocks = nb;
-      if (resu != a) { double* t = a; a = b2; b2 = t; }
+      if (resu != a) { TV* t = a; a = b2; b2 = t; }
       done = 2;
     } else {
-      const int nb = op_jacobi(H, l, rhs[l], nullptr, a, (only && sweeps == 1) ? rz_part : nullptr, st);
+      const int nb = op_jacobi<TV>(H, l, rhs[l], nullptr, a, H.omega[0], (only && sweeps == 1) ? rz_part : nullptr, st);
       if (only && sweeps == 1 && rz_blocks) *rz_blocks = nb;
       done = 1;
     }
     for (int s = done; s < sweeps; ++s) {
-      const int nb = op_jacobi(H, l, rhs[l], a, b2, (only && s == sweeps - 1) ? rz_part : nullptr, st);
+      const int nb = op_jacobi<TV>(H, l, rhs[l], a, b2, H.omega[s % H.nu],
+                                   (only && s == sweeps - 1) ? rz_part : nullptr, st);
       if (only && s == sweeps - 1 && rz_blocks) *rz_blocks = nb;
-      double* t = a; a = b2; b2 = t;
+      TV* t = a; a = b2; b2 = t;
     }
     cur[l] = a;
     if (l < last) {
-      op_residual(H, l, rhs[l], a, H.res[l], nullptr, st);
+      op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
-      LAUNCH(mg_restrict_kernel, C.n, L, C, (const double*)H.res[l], H.rhs[l + 1], H.Bp);
-      rhs[l + 1] = H.rhs[l + 1];
+      LAUNCH(mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
+      rhs[l + 1] = (const TV*)H.rhs[l + 1];
     }
   }
   for (int l = last - 1; l >= 0; --l) {  // upward leg
     const Level& L = H.lev[l];
     const Level& C = H.lev[l + 1];
-    double* a = cur[l];
-    double* b2 = (a == H.xa[l]) ? H.xb[l] : H.xa[l];
-    LAUNCH(mg_prolong_add_kernel, L.n, L, C, (const double*)cur[l + 1], a, H.Bp);
+    TV* a = cur[l];
+    TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
+    LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
     for (int s = 0; s < H.nu; ++s) {
       const bool lastsweep = (l == 0 && s == H.nu - 1);
-      const int nb = op_jacobi(H, l, rhs[l], a, b2, lastsweep ? rz_part : nullptr, st);
+      const int nb = op_jacobi<TV>(H, l, rhs[l], a, b2, H.omega[H.nu - 1 - s], lastsweep ? rz_part : nullptr, st);
       if (lastsweep && rz_blocks) *rz_blocks = nb;
-      double* t = a; a = b2; b2 = t;
+      TV* t = a; a = b2; b2 = t;
     }
     cur[l] = a;
   }
@@ -623,11 +638,11 @@ double* vcycle(const Hier& H, const double* rhs0, double* rz_part, int* rz_block
 // C ABI
 // =========================================================================================
 static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int Bv, int Bp, const double* scale,
-                     double omega, int nu, int n_coarse) {
+                     const double* omegas, int nu, int n_coarse) {
   if (!levels || n_levels < 1 || n_levels > kMaxLevels) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
-  if (nu < 1 || n_coarse < 1) return DIFFHE_E_BADARG;
+  if (nu < 1 || nu > 8 || n_coarse < 1 || !omegas) return DIFFHE_E_BADARG;
   for (int l = 0; l < n_levels; ++l) {
     const diffhe_mg_level& s = levels[l];
     if (s.nx < 2 || s.ny < 2 || (s.nd != 3 && s.nd != 4) || !s.vals || !s.is_bc) return DIFFHE_E_BADARG;
@@ -637,46 +652,57 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
     L.v = s.vals; L.bc = s.is_bc;
   }
-  H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.omega = omega; H.nu = nu; H.n_coarse = n_coarse;
+  H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
+  for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
 }
 
-static long long carve(Hier& H, double* work) {
+// V-cycle vectors, carved in units of doubles (fp32 vectors take half, rounded up to 64 B)
+static long long carve(Hier& H, double* work, bool fp32) {
   long long off = 0;
-  auto take = [&](long long cnt) { double* p = work ? work + off : nullptr; off += cnt; return p; };
+  auto take = [&](long long cnt) {
+    if (fp32) cnt = (cnt + 1) / 2;
+    cnt = (cnt + 7) & ~7LL;
+    double* p = work ? work + off : nullptr;
+    off += cnt;
+    return (void*)p;
+  };
   for (int l = 0; l < H.nl; ++l) {
     const long long nb = (long long)H.lev[l].n * H.Bp;
     H.xa[l] = take(nb);
     H.xb[l] = take(nb);
     H.res[l] = take(nb);
-    H.rhs[l] = l > 0 ? take(nb) : nullptr;
+    H.rhs[l] = (l > 0 || fp32) ? take(nb) : nullptr;  // level 0, fp32: the fp32 copy of the CG residual
   }
   return off;
 }
 
 extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp) {
   Hier H;
-  if (fill_hier(H, levels, n_levels, 1, Bp, nullptr, 0.8, 1, 1)) return -1;
+  const double w1 = 0.8;
+  if (fill_hier(H, levels, n_levels, 1, Bp, nullptr, &w1, 1, 1)) return -1;
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = lgrid(H.lev[0].n, Bp).x;
   (void)nblk;
-  return carve(H, nullptr) + 3 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;
+  return carve(H, nullptr, false) + 3 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;  // fp64 layout is the larger
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
                                         const double* b, double* x, int Bp, double tol, int max_iter, int nu,
-                                        int n_coarse, double omega, double* work, double* relres, int* iters,
-                                        int* status_host, void* stream) {
+                                        int n_coarse, const double* omegas_host, int precond_fp32, double* work,
+                                        double* relres, int* iters, int* status_host, void* stream) {
   if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0) return DIFFHE_E_BADARG;
   Hier H;
-  int rc = fill_hier(H, levels, n_levels, Bv, Bp, scale, omega, nu, n_coarse);
+  int rc = fill_hier(H, levels, n_levels, Bv, Bp, scale, omegas_host, nu, n_coarse);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const Level& L0 = H.lev[0];
   const int n = L0.n;
   const long long nb = (long long)n * Bp;
   const int nblk = lgrid(n, Bp).x;
-  double* w = work + carve(H, work);
+  const bool f32 = precond_fp32 != 0;
+  double* w = work + carve(H, work, f32);
+  float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;
   double* p = r + nb;
   double* Ap = p + nb;
@@ -693,11 +719,21 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
 
   int nbz = 0, nba = 0;
-  LAUNCH(pcg_init_kernel, n, b, x, r, partA, n, Bp);
+  LAUNCH(pcg_init_kernel, n, b, x, r, r32, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
-  double* z = vcycle(H, r, partB, &nbz, st);
-  SCALAR(S_RZ0, partB, nbz);
-  LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 1, n, Bp);
+  // z = M^-1 r, then p = z + beta p (first: p = z); the V-cycle's last sweep leaves r.z partials
+  auto precondition = [&](int first) {
+    if (f32) {
+      const float* z = vcycle<float>(H, (const float*)r32, partB, &nbz, st);
+      SCALAR(first ? S_RZ0 : S_BETA, partB, nbz);
+      LAUNCH(pcg_update_p_kernel<float>, n, z, (const double*)S.beta, p, first, n, Bp);
+    } else {
+      const double* z = vcycle<double>(H, (const double*)r, partB, &nbz, st);
+      SCALAR(first ? S_RZ0 : S_BETA, partB, nbz);
+      LAUNCH(pcg_update_p_kernel<double>, n, z, (const double*)S.beta, p, first, n, Bp);
+    }
+  };
+  precondition(1);
   rc = diffhe::check_launch();
   if (rc) return rc;
 
@@ -705,21 +741,19 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   while (it < max_iter) {
     nba = op_apply_dot(H, p, Ap, partA, st);
     SCALAR(S_ALPHA, partA, nba);
-    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, x, r, partA, n, Bp);
+    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, x, r, r32, partA, n, Bp);
     SCALAR(S_CONV, partA, nblk);
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
     if (rc) return rc;
     // overlap the convergence read-back with the next V-cycle: enqueue it first, then wait
-    z = vcycle(H, r, partB, &nbz, st);
-    SCALAR(S_BETA, partB, nbz);
-    LAUNCH(pcg_update_p_kernel, n, (const double*)z, (const double*)S.beta, p, 0, n, Bp);
+    precondition(0);
     rc = diffhe::check(hipStreamSynchronize(st));
     if (rc) return rc;
     n_active = status_host[2];
     if (n_active == 0) break;
   }
-  nba = op_residual(H, 0, b, x, nullptr, partA, st);
+  nba = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
   SCALAR(S_RELRES, partA, nba);
   rc = diffhe::check_launch();
   if (rc) return rc;
@@ -734,7 +768,8 @@ extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const 
                                     double* y, double* part, int Bp, void* stream) {
   if (!x || !y || !part) return DIFFHE_E_BADARG;
   Hier H;
-  int rc = fill_hier(H, level, 1, Bv, Bp, scale, 0.8, 1, 1);
+  const double w1 = 0.8;
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, &w1, 1, 1);
   if (rc) return rc;
   op_apply_dot(H, x, y, part, (hipStream_t)stream);
   return diffhe::check_launch();
@@ -744,9 +779,9 @@ extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const
                                      const double* xin, double* xout, double omega, int Bp, void* stream) {
   if (!rhs || !xout) return DIFFHE_E_BADARG;
   Hier H;
-  int rc = fill_hier(H, level, 1, Bv, Bp, scale, omega, 1, 1);
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, &omega, 1, 1);
   if (rc) return rc;
-  op_jacobi(H, 0, rhs, xin, xout, nullptr, (hipStream_t)stream);
+  op_jacobi<double>(H, 0, rhs, xin, xout, omega, nullptr, (hipStream_t)stream);
   return diffhe::check_launch();
 }
 

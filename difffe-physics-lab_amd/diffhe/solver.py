@@ -15,6 +15,8 @@ Extensions over the reference (which has no batch dimension, solver.py:54):
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -221,8 +223,12 @@ class _Engine:
         work = torch.empty(L.diffhe_lattice_pcg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
         iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        # per-sweep Jacobi damping: Chebyshev weights for the interval [0.5, 2] of D^-1 A when nu == 2
+        omegas = mg.get("omegas") or ([0.56, 1.39] if mg["nu"] == 2 else [mg["omega"]] * mg["nu"])
+        om = (ctypes.c_double * len(omegas))(*omegas)
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
-                                              self.max_iter, mg["nu"], mg["n_coarse"], mg["omega"], _hip.ptr(work),
+                                              self.max_iter, len(omegas), mg["n_coarse"], om,
+                                              int(mg.get("fp32", 0)), _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
                                               _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
@@ -389,7 +395,13 @@ class DifferentiableFESolver(nn.Module):
         if method not in ("auto", "ell"):
             raise ValueError(f"Unknown method: {method!r}")
         self.method = method      # "ell" forces the general path on lattice meshes
-        self.mg = dict(nu=2, n_coarse=8, omega=0.8)
+        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=0)
+        for item in filter(None, os.environ.get("DIFFHE_MG", "").split(",")):   # e.g. "nu=1,omega=0.85"
+            key, val = item.split("=")
+            if key == "omegas":
+                self.mg[key] = [float(v) for v in val.split(":")]
+            else:
+                self.mg[key] = float(val) if key == "omega" else int(val)
         self.mg.update(mg or {})
         self._device = device
         self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly

@@ -163,20 +163,24 @@ typedef struct diffhe_mg_level {
   const unsigned char* is_bc;  /* (n) */
 } diffhe_mg_level;
 
-/* Batched CG preconditioned by one multigrid V(nu,nu) cycle (damped Jacobi omega, P1
- * transfers, n_coarse sweeps on the last level; n_levels == 1 degenerates to a Jacobi
- * polynomial).  Replaces torch.linalg.solve (solver.py:174) forward and adjoint.
+/* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
+ * per-sweep damping factors omegas_host[0..nu-1] -- Chebyshev weights; post-smoothing runs
+ * them in reverse so the cycle stays symmetric -- P1 transfers, n_coarse sweeps on the last
+ * level; n_levels == 1 degenerates to a Jacobi polynomial).  Replaces torch.linalg.solve
+ * (solver.py:174) forward and adjoint.
  *   levels   HOST array of n_levels descriptors (device pointers inside)
  *   Bv       Bp (matrix per sample) or 1 (shared); scale (Bp) or NULL: K_b = scale[b]*K on
  *            the free rows (one scalar kappa per sample, solver.py:88,139)
+ *   precond_fp32  != 0: the V-cycle stores its vectors in fp32 (arithmetic stays fp64 in
+ *            registers; the outer CG, its residual and all dot products are fp64)
  *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */
 long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp);
 int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
                              const double* b, double* x, int Bp, double tol, int max_iter, int nu, int n_coarse,
-                             double omega, double* work, double* relres, int* iters, int* status_host,
-                             void* stream);
+                             const double* omegas_host, int precond_fp32, double* work, double* relres,
+                             int* iters, int* status_host, void* stream);
 /* Single kernels of that loop, exposed for timing/tests: y = A x (+ x.y block partials in
  * `part`, diffhe_lattice_blocks(n, Bp) * Bp doubles) and one damped-Jacobi sweep
  * xout = xin + omega (rhs - A xin)/D  (xin NULL = 0). */
