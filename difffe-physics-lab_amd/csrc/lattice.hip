@@ -133,15 +133,39 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
 // applied to every row without looking up the Dirichlet flag (0 * s_b == 0).
 // ---------------------------------------------------------------------------------------------
 enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
+// Fusions folded into the window load:
+//   F_PROLONG: the operand is x + P e (coarse-grid correction added on the fly; with M_JACOBI this
+//              is "prolongate, correct and post-smooth" in one pass);
+//   F_PUPD:    the operand is the NEW search direction p = z + beta p_old of the CG (with M_APPLY
+//              this is "update p, apply A, dot p.Ap" in one pass); the kernel also stores p and
+//              applies the pending iterate update x += alpha_prev p_old.
+enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2 };
 
-template <typename TV, int MODE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
+struct Extra {
+  const void* a0;           // F_PROLONG: coarse correction e (TA);  F_PUPD: z (TA)
+  const double* p_in;       // F_PUPD
+  double* p_out;            // F_PUPD
+  double* x;                // F_PUPD: iterate, updated in place
+  const double* alpha;      // F_PUPD: per-sample alpha of the previous iteration
+  const double* beta;       // F_PUPD
+  int first;                // F_PUPD: first iteration (p = z, nothing pending)
+  int cW;                   // F_PROLONG: row width of the coarse level
+  const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there)
+};
+
+template <typename TV, typename TA, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
 __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV* __restrict__ src,
                                              const TV* __restrict__ bvec, TV* __restrict__ out, double omega,
-                                             double omega_in, int Bp, int b, int c0w, int r0, int r1) {
+                                             double omega_in, const Extra& ex, int Bp, int b, int c0w, int r0,
+                                             int r1) {
   const int W = L.W, nyp = L.ny + 1;
   const i64 n = L.n;
   const i64 Bv = SHARED ? 1 : Bp;
-  const i64 vb = SHARED ? 0 : b;
+  // Addressing discipline: every pointer below is WAVE-UNIFORM (lives in SGPRs) and the lane's
+  // sample index is added last as a 32-bit offset, so loads/stores use the "SGPR base + VGPR
+  // offset" form and the kernel needs one address VGPR instead of one 64-bit pair per stream.
+  const unsigned lb = (unsigned)b;            // lane offset into (.., Bp) vectors
+  const unsigned lv = SHARED ? 0u : (unsigned)b;  // lane offset into the matrix values
   double s = 0.0;
 
   // Column offsets of the window (q <-> grid column c0w - 1 + q) and of the strip (k <-> c0w + k),
@@ -160,20 +184,59 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   // D_k[i] lives at V[(k*n + i)*Bv + vb]; for k >= 1 a negative i (>= -n) still indexes valid,
   // finite memory (the previous diagonal) and is only ever multiplied by a window value of 0.
   const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
-  const double* __restrict__ p0 = L.v + vb + i0 * Bv;
+  const double* __restrict__ p0 = L.v + i0 * Bv;
   const double* __restrict__ p1 = p0 + n * Bv;
   const double* __restrict__ p2 = p1 + n * Bv;
   const double* __restrict__ p3 = p2 + n * Bv;
-  const TV* __restrict__ px = src + i0 * Bp + b;
-  const TV* __restrict__ pb = bvec ? bvec + i0 * Bp + b : nullptr;
-  TV* __restrict__ po = out ? out + i0 * Bp + b : nullptr;
+  const TV* __restrict__ px = src + i0 * Bp;
+  const TV* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
+  TV* __restrict__ po = out ? out + i0 * Bp : nullptr;
   const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
 
-  auto load_window = [&](const TV* __restrict__ xrow, const double* __restrict__ d0row, double* dst) {
+  const double beta = (FUSE == F_PUPD && !ex.first) ? ex.beta[b] : 0.0;
+  const double alpha_prev = (FUSE == F_PUPD && !ex.first) ? ex.alpha[b] : 0.0;
+  const TA* __restrict__ aux = (const TA*)ex.a0;
+  // F_PUPD row pointers at (row, c0w), advanced with the others
+  const TA* __restrict__ pz = (FUSE == F_PUPD) ? aux + i0 * Bp : nullptr;
+  const double* __restrict__ ppi = (FUSE == F_PUPD) ? ex.p_in + i0 * Bp : nullptr;
+  double* __restrict__ ppo = (FUSE == F_PUPD) ? ex.p_out + i0 * Bp : nullptr;
+  double* __restrict__ pxx = (FUSE == F_PUPD) ? ex.x + i0 * Bp : nullptr;
+
+  // `row` is the grid row being loaded; xrow / d0row point at (row, c0w); roff = offset of that
+  // row from the current one in vector elements
+  auto load_window = [&](int row, i64 roff, const TV* __restrict__ xrow, const double* __restrict__ d0row,
+                         double* dst) {
+    double ce[RW / 2 + 2], ce2[RW / 2 + 2];
+    if (FUSE == F_PROLONG) {  // coarse values around this strip: coarse columns c0w/2 - 1 + j
+      const int cr = row >> 1;
+#pragma unroll
+      for (int j = 0; j < RW / 2 + 2; ++j) {
+        int cj = (c0w >> 1) - 1 + j;
+        cj = cj < 0 ? 0 : (cj > ex.cW - 1 ? ex.cW - 1 : cj);
+        ce[j] = (double)(aux + ((i64)cr * ex.cW + cj) * Bp)[lb];
+        ce2[j] = (row & 1) ? (double)(aux + ((i64)(cr + 1) * ex.cW + cj) * Bp)[lb] : 0.0;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < RW + 2; ++q) {
-      double v = (double)xrow[(i64)dq[q] * Bp];
-      if (XFROMB) v = omega_in * v / (sb * d0row[(i64)dq[q] * Bv]);
+      double v;
+      if (FUSE == F_PUPD) {
+        const i64 o = roff + (i64)dq[q] * Bp;
+        v = (double)(pz + o)[lb];
+        if (!ex.first) v += beta * (ppi + o)[lb];
+      } else {
+        v = (double)(xrow + (i64)dq[q] * Bp)[lb];
+      }
+      if (XFROMB) v = omega_in * v / (sb * (d0row + (i64)dq[q] * Bv)[lv]);
+      if (FUSE == F_PROLONG) {
+        double corr;  // c0w is even: window column q has the parity of q + 1
+        if (q & 1)
+          corr = (row & 1) ? 0.5 * (ce[(q - 1) / 2 + 1] + ce2[(q - 1) / 2 + 1]) : ce[(q - 1) / 2 + 1];
+        else
+          corr = (row & 1) ? 0.5 * (ce[q / 2 + 1] + ce2[q / 2]) : 0.5 * (ce[q / 2] + ce[q / 2 + 1]);
+        if (ex.bc[(i64)row * W + c0w + dq[q]]) corr = 0.0;
+        v += corr;
+      }
       dst[q] = okq[q] ? v : 0.0;
     }
   };
@@ -182,16 +245,16 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   double n2p[RW], d3p[RW + 1];
 #pragma unroll
   for (int q = 0; q < RW + 2; ++q) xm[q] = 0.0;
-  if (r0 > 0) load_window(px - rowX, p0 - rowV, xm);
-  load_window(px, p0, xc);
+  if (r0 > 0) load_window(r0 - 1, -rowX, px - rowX, p0 - rowV, xm);
+  load_window(r0, 0, px, p0, xc);
 #pragma unroll
-  for (int k = 0; k < RW; ++k) n2p[k] = (p2 - rowV)[(i64)dq[k + 1] * Bv];
+  for (int k = 0; k < RW; ++k) n2p[k] = (p2 - rowV + (i64)dq[k + 1] * Bv)[lv];
 #pragma unroll
-  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (p3 - rowV)[(i64)dq[k + 1] * Bv] : 0.0;
+  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (p3 - rowV + (i64)dq[k + 1] * Bv)[lv] : 0.0;
 
   for (int row = r0; row < r1; ++row) {
     if (row + 1 < nyp) {
-      load_window(px + rowX, p0 + rowV, xp);
+      load_window(row + 1, rowX, px + rowX, p0 + rowV, xp);
     } else {
 #pragma unroll
       for (int q = 0; q < RW + 2; ++q) xp[q] = 0.0;
@@ -199,16 +262,16 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     double d0[RW], e1[RW + 1], n2c[RW], d3c[RW + 1];
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
-      d0[k] = p0[(i64)dq[k + 1] * Bv];
-      n2c[k] = p2[(i64)dq[k + 1] * Bv];
+      d0[k] = (p0 + (i64)dq[k + 1] * Bv)[lv];
+      n2c[k] = (p2 + (i64)dq[k + 1] * Bv)[lv];
     }
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) {
       // east coupling of column c0w-1+k; column -1 reads the element before the row (valid
       // memory, multiplied by a zero window value)
       const int dc = TAIL ? dq[k] : k - 1;
-      e1[k] = p1[(i64)dc * Bv];
-      d3c[k] = (ND == 4) ? p3[(i64)dq[k + 1] * Bv] : 0.0;
+      e1[k] = (p1 + (i64)dc * Bv)[lv];
+      d3c[k] = (ND == 4) ? (p3 + (i64)dq[k + 1] * Bv)[lv] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -221,17 +284,21 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       const i64 o = (i64)k * Bp;
       if (MODE == M_APPLY) {
         const double y = sb * acc;
-        po[o] = (TV)y;
+        (po + o)[lb] = (TV)y;
         s += y * xc[q];
+        if (FUSE == F_PUPD) {  // store the new direction; apply the pending x += alpha_prev * p_old
+          (ppo + o)[lb] = xc[q];
+          if (!ex.first) (pxx + o)[lb] += alpha_prev * (ppi + o)[lb];
+        }
       } else {
-        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega_in : (double)pb[o];
+        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega_in : (double)(pb + o)[lb];
         const double res = bi - sb * acc;
         if (MODE == M_RESID) {
-          if (po) po[o] = (TV)res;
+          if (po) (po + o)[lb] = (TV)res;
           s += res * res;
         } else {
           const double xo = xc[q] + omega * res / (sb * d0[k]);
-          po[o] = (TV)xo;
+          (po + o)[lb] = (TV)xo;
           s += bi * xo;
         }
       }
@@ -249,16 +316,17 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     px += rowX;
     if (pb) pb += rowX;
     if (po) po += rowX;
+    if (FUSE == F_PUPD) { pz += rowX; ppi += rowX; ppo += rowX; pxx += rowX; }
   }
   return s;
 }
 
-template <typename TV, int MODE, int ND, bool SHARED, bool XFROMB, int RW>
+template <typename TV, typename TA, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW>
 __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
                                                          const TV* __restrict__ xin, const TV* __restrict__ bvec,
-                                                         TV* __restrict__ out,
-                                                         double omega, double omega_in, double* __restrict__ part,
-                                                         int Bp, int ncb, int TR) {
+                                                         TV* __restrict__ out, double omega, double omega_in,
+                                                         Extra ex, double* __restrict__ part, int Bp, int ncb,
+                                                         int TR) {
   __shared__ double lds[4 * kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -273,9 +341,11 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
   double s = 0.0;
   if (c0w < L.W && r0 < r1) {
     if (c0w + RW + 1 > L.W)
-      s = strip_body<TV, MODE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, Bp, b, c0w, r0, r1);
+      s = strip_body<TV, TA, MODE, FUSE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
+                                                                       c0w, r0, r1);
     else
-      s = strip_body<TV, MODE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, Bp, b, c0w, r0, r1);
+      s = strip_body<TV, TA, MODE, FUSE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
+                                                                        c0w, r0, r1);
   }
   if (part) {
     const double t = block_sum_per_sample(s, Bp, lds);
@@ -308,13 +378,14 @@ inline StripGeom strip_geom(const Level& L, int Bp) {
   return g;
 }
 
-template <typename TV, int MODE, bool XFROMB>
+template <typename TV, int MODE, bool XFROMB, int FUSE = F_NONE, typename TA = TV>
 void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, const TV* bvec, TV* out,
-                  double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st) {
+                  double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st,
+                  const Extra& ex = Extra{}) {
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
-#define STRIP(ND_, SH_)                                                                                          \
-  hipLaunchKernelGGL((dia_strip_kernel<TV, MODE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, scale, xin, \
-                     bvec, out, omega, omega_in, part, Bp, g.ncb, g.TR)
+#define STRIP(ND_, SH_)                                                                                            \
+  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, MODE, FUSE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, \
+                     scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
   if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true); else STRIP(3, false);
   } else {
@@ -418,13 +489,24 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    x[o] += a * p[o];
+    if (x) x[o] += a * p[o];  // x == NULL: the iterate update is fused into the next operator apply
     const double ri = r[o] - a * Ap[o];
     r[o] = ri;
     if (r32) r32[o] = (float)ri;
     s += ri * ri;
   }
   STORE_PARTIAL(part, s);
+}
+
+// x += alpha p  (flush of the pending iterate update of the fused CG loop)
+__global__ __launch_bounds__(256) void pcg_axpy_kernel(const double* __restrict__ alpha, const double* __restrict__ p,
+                                                        double* __restrict__ x, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  const double a = alpha[nm.b];
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    x[o] += a * p[o];
+  }
 }
 
 // p = z + beta p   (first: p = z)
@@ -620,8 +702,21 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     const Level& C = H.lev[l + 1];
     TV* a = cur[l];
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
-    LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
-    for (int s = 0; s < H.nu; ++s) {
+    int s0 = 0;
+    const StripGeom g = strip_geom(L, H.Bp);
+    if (g.use) {  // prolongate + correct + first post-sweep in one pass
+      const bool lastsweep = (l == 0 && H.nu == 1);
+      Extra ex{};
+      ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
+      launch_strip<TV, M_JACOBI, false, F_PROLONG, TV>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2, H.omega[H.nu - 1], 0.0,
+                                                        lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      if (lastsweep && rz_blocks) *rz_blocks = g.ncb * g.nrc;
+      TV* t = a; a = b2; b2 = t;
+      s0 = 1;
+    } else {
+      LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
+    }
+    for (int s = s0; s < H.nu; ++s) {
       const bool lastsweep = (l == 0 && s == H.nu - 1);
       const int nb = op_jacobi<TV>(H, l, rhs[l], a, b2, H.omega[H.nu - 1 - s], lastsweep ? rz_part : nullptr, st);
       if (lastsweep && rz_blocks) *rz_blocks = nb;
@@ -684,7 +779,7 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = lgrid(H.lev[0].n, Bp).x;
   (void)nblk;
-  return carve(H, nullptr, false) + 3 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;  // fp64 layout is the larger
+  return carve(H, nullptr, false) + 4 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;  // fp64 layout is the larger
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
@@ -706,7 +801,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   double* r = w;
   double* p = r + nb;
   double* Ap = p + nb;
-  double* partA = Ap + nb;
+  double* p2 = Ap + nb;  // second direction buffer: the fused apply reads p_old with halos, so p ping-pongs
+  double* partA = p2 + nb;
   double* partB = partA + (long long)kPartBlocks * Bp;
   double* sc = partB + (long long)kPartBlocks * Bp;
   PcgScalars S;
@@ -721,16 +817,34 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   int nbz = 0, nba = 0;
   LAUNCH(pcg_init_kernel, n, b, x, r, r32, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
-  // z = M^-1 r, then p = z + beta p (first: p = z); the V-cycle's last sweep leaves r.z partials
+  // Fused loop (fine level runs the strip kernels): per iteration
+  //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
+  //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
+  // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
+  const StripGeom g0 = strip_geom(L0, Bp);
+  const bool fused = g0.use;
+  const void* z = nullptr;
   auto precondition = [&](int first) {
-    if (f32) {
-      const float* z = vcycle<float>(H, (const float*)r32, partB, &nbz, st);
-      SCALAR(first ? S_RZ0 : S_BETA, partB, nbz);
-      LAUNCH(pcg_update_p_kernel<float>, n, z, (const double*)S.beta, p, first, n, Bp);
+    if (f32) z = vcycle<float>(H, (const float*)r32, partB, &nbz, st);
+    else z = vcycle<double>(H, (const double*)r, partB, &nbz, st);
+    SCALAR(first ? S_RZ0 : S_BETA, partB, nbz);
+  };
+  auto apply_step = [&](int first) {
+    if (fused) {
+      Extra ex{};
+      ex.a0 = z; ex.p_in = p; ex.p_out = p2; ex.x = x; ex.alpha = S.alpha; ex.beta = S.beta; ex.first = first;
+      if (f32)
+        launch_strip<double, M_APPLY, false, F_PUPD, float>(L0, Bv, scale, (const double*)nullptr,
+                                                            (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
+      else
+        launch_strip<double, M_APPLY, false, F_PUPD, double>(L0, Bv, scale, (const double*)nullptr,
+                                                             (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
+      double* t = p; p = p2; p2 = t;
+      nba = g0.ncb * g0.nrc;
     } else {
-      const double* z = vcycle<double>(H, (const double*)r, partB, &nbz, st);
-      SCALAR(first ? S_RZ0 : S_BETA, partB, nbz);
-      LAUNCH(pcg_update_p_kernel<double>, n, z, (const double*)S.beta, p, first, n, Bp);
+      if (f32) LAUNCH(pcg_update_p_kernel<float>, n, (const float*)z, (const double*)S.beta, p, first, n, Bp);
+      else LAUNCH(pcg_update_p_kernel<double>, n, (const double*)z, (const double*)S.beta, p, first, n, Bp);
+      nba = op_apply_dot(H, p, Ap, partA, st);
     }
   };
   precondition(1);
@@ -739,9 +853,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 
   int it = 0, n_active = -1;
   while (it < max_iter) {
-    nba = op_apply_dot(H, p, Ap, partA, st);
+    apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
-    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, x, r, r32, partA, n, Bp);
+    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
+           r, r32, partA, n, Bp);
     SCALAR(S_CONV, partA, nblk);
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -753,6 +868,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     n_active = status_host[2];
     if (n_active == 0) break;
   }
+  if (fused && it > 0) LAUNCH(pcg_axpy_kernel, n, (const double*)S.alpha, (const double*)p, x, n, Bp);
   nba = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
   SCALAR(S_RELRES, partA, nba);
   rc = diffhe::check_launch();
