@@ -102,12 +102,27 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     value = world * B * args.steps / elapsed
 
+    # secondary measurement, same run: V-cycle vectors stored in fp64 instead of fp32
+    variant = None
+    if rank == 0 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32"):
+        solver.mg["fp32"] = 0
+        step()
+        torch.cuda.synchronize(dev)
+        tv = time.perf_counter()
+        step()
+        torch.cuda.synchronize(dev)
+        tv = time.perf_counter() - tv
+        variant = {"vcycle_storage_fp64": {"value_per_gpu": round(B / tv, 3), "ms_per_step": round(1e3 * tv, 3),
+                                           "iters_fwd": solver.last_info.iterations}}
+        solver.mg["fp32"] = 1
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: the batched operator apply of the CG loop ----
         L = _hip.lib()
         Bp = padded_batch(B)
         roof = None
+        traffic = None
         st = torch.cuda.current_stream(dev).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -136,6 +151,16 @@ def main():
                 "diffhe_lattice_smooth"))
             alg_bytes = 24.0 * n * Bp           # read x, rhs; write x (matrix is batch-shared: amortised)
             kname = "dia_strip_kernel<M_JACOBI> (fine-level Jacobi sweep)"
+            # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same sizes;
+            # FETCH_SIZE doubled per the guide's gfx950 correction) -- only valid for the contract workload
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    pmc = json.load(fh)
+                if pmc["pass_bytes"] == 8 * n * Bp:
+                    key = [k for k in pmc["kernels"] if "dia_strip_kernel<double, double, 2, 0" in k][0]
+                    traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             del x, rhs, y, vals
         elif not plan.is_chain:
             W = plan.W
@@ -152,7 +177,7 @@ def main():
         if not plan.is_chain:
             achieved = alg_bytes / dur / 1e9
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4)}
 
         # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------
@@ -183,11 +208,14 @@ def main():
             "config": {"workload": f"C4: rectangle({N},{N}), {B} samples/GPU, kappa_b~U(0.5,2) scalar per sample, "
                                    f"f=1, L=mean_b sum u^2, fwd+adjoint", "mesh": f"{N}x{N}", "batch_per_gpu": B,
                        "global_batch": B * world, "solver": solver.last_info.path, "tol": solver.tol,
+                       "multigrid": {k: v for k, v in solver.mg.items() if v is not None},
+                       "precision": "fp64 arithmetic, CG vectors, residuals and dots; V-cycle (preconditioner) "
+                                    "vectors stored fp32" if solver.mg.get("fp32") else "fp64 throughout",
                        "parallelism": f"batch-sharded x{world}"},
             "solver_iters": {"fwd": int(it[:, 0].max()), "adj": int(it[:, 1].max()),
                              "max_relres_fwd": float(it[:, 2].max()), "max_relres_adj": float(it[:, 3].max()),
                              "not_converged": int(it[:, 4].max())},
-            "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity, "variants": variant,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -361,11 +361,11 @@ struct StripGeom {
   int ncb, nrc, TR;
 };
 
-inline StripGeom strip_geom(const Level& L, int Bp) {
+inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols) {
   StripGeom g{false, 0, 0, 0};
   if (Bp < kWave || L.W < 4 * kStripCols || L.ny + 1 < 16) return g;
   g.use = true;
-  g.ncb = (L.W + 4 * kStripCols - 1) / (4 * kStripCols);
+  g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
   const int gy = Bp / kWave;
   static const int target = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
   int nrc = (target + g.ncb * gy - 1) / (g.ncb * gy);
@@ -378,13 +378,13 @@ inline StripGeom strip_geom(const Level& L, int Bp) {
   return g;
 }
 
-template <typename TV, int MODE, bool XFROMB, int FUSE = F_NONE, typename TA = TV>
+template <typename TV, int MODE, bool XFROMB, int FUSE = F_NONE, typename TA = TV, int RW = kStripCols>
 void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, const TV* bvec, TV* out,
                   double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st,
                   const Extra& ex = Extra{}) {
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
 #define STRIP(ND_, SH_)                                                                                            \
-  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, MODE, FUSE, ND_, SH_, XFROMB, kStripCols>), grid, dim3(256), 0, st, L, \
+  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, MODE, FUSE, ND_, SH_, XFROMB, RW>), grid, dim3(256), 0, st, L, \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
   if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true); else STRIP(3, false);
@@ -821,7 +821,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
   // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
-  const StripGeom g0 = strip_geom(L0, Bp);
+  constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused kernel: fewer VGPRs, more waves
+  const StripGeom g0 = strip_geom(L0, Bp, kPupdCols);
   const bool fused = g0.use;
   const void* z = nullptr;
   auto precondition = [&](int first) {
@@ -834,10 +835,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       Extra ex{};
       ex.a0 = z; ex.p_in = p; ex.p_out = p2; ex.x = x; ex.alpha = S.alpha; ex.beta = S.beta; ex.first = first;
       if (f32)
-        launch_strip<double, M_APPLY, false, F_PUPD, float>(L0, Bv, scale, (const double*)nullptr,
+        launch_strip<double, M_APPLY, false, F_PUPD, float, kPupdCols>(L0, Bv, scale, (const double*)nullptr,
                                                             (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
       else
-        launch_strip<double, M_APPLY, false, F_PUPD, double>(L0, Bv, scale, (const double*)nullptr,
+        launch_strip<double, M_APPLY, false, F_PUPD, double, kPupdCols>(L0, Bv, scale, (const double*)nullptr,
                                                              (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
       double* t = p; p = p2; p2 = t;
       nba = g0.ncb * g0.nrc;

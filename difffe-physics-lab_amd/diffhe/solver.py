@@ -395,7 +395,9 @@ class DifferentiableFESolver(nn.Module):
         if method not in ("auto", "ell"):
             raise ValueError(f"Unknown method: {method!r}")
         self.method = method      # "ell" forces the general path on lattice meshes
-        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=0)
+        # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
+        # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
+        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1)
         for item in filter(None, os.environ.get("DIFFHE_MG", "").split(",")):   # e.g. "nu=1,omega=0.85"
             key, val = item.split("=")
             if key == "omegas":
