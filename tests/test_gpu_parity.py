@@ -427,3 +427,65 @@ def test_lattice_operator_kernels_vs_dense():
             assert rel_err(y[:, b].cpu().numpy(), yref) < 1e-13
             xref = x[:, b] + 0.8 * (rhs[:, b] - yref) / np.diag(K)
             assert rel_err(xo[:, b].cpu().numpy(), xref) < 1e-13
+
+
+def _dst_solve_unit_square(N, kappa, F_interior):
+    """Exact solve of kappa * (5-point Laplacian) u = F on the (N-1)^2 interior nodes of the
+    uniform unit square via DST-I (K_free = kappa * (diag 4, off -1))."""
+    from scipy.fft import dstn, idstn
+    k = np.arange(1, N)
+    lam = 4.0 - 2.0 * np.cos(np.pi * k / N)[:, None] - 2.0 * np.cos(np.pi * k / N)[None, :]
+    return idstn(dstn(F_interior, type=1) / (kappa * lam), type=1)
+
+
+@pytest.mark.parametrize("N,B", [(256, 64), (1024, 64)])
+def test_full_size_properties_and_exact_dst(N, B):
+    """BASELINE-size checks that need no O(n^3) oracle: (i) the exact DST-I solution of the
+    assembled 5-point system for random f, (ii) dL/dkappa = -<gbar,u>/kappa = -2L/kappa,
+    (iii) linearity in f, (iv) homogeneity u(c*kappa) = u(kappa)/c."""
+    mesh = FEMesh.rectangle(N, N)
+    n = mesh.n_nodes
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(4096)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(dev).requires_grad_(True)
+    f = (1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)).to(dev)
+    solver = DifferentiableFESolver(mesh, kappa)
+    u = solver(f)
+    assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.not_converged == 0
+    L = (u ** 2).sum(dim=1)
+    L.sum().backward()
+    ref = -2.0 * L.detach() / kappa.detach()
+    assert float(((kappa.grad - ref).abs() / ref.abs()).max()) < RTOL_GRAD
+    # (i) exact discrete solution: F = M f restricted to the interior (oracle load vector), DST solve
+    nodes, el, bn, bv = arrays(mesh)
+    for b in (0, B - 1):
+        F = orc.load_vector(nodes, el, f[b].cpu().numpy()).reshape(N + 1, N + 1)[1:-1, 1:-1]
+        ue = np.zeros((N + 1, N + 1))
+        ue[1:-1, 1:-1] = _dst_solve_unit_square(N, float(kappa[b]), F)
+        assert rel_err(u[b].detach().cpu().numpy(), ue.ravel()) < RTOL_U
+    # (iii) linearity in f and (iv) homogeneity in kappa, on the first 64 samples
+    with torch.no_grad():
+        u2 = DifferentiableFESolver(mesh, 2.0 * kappa.detach())(3.0 * f)
+    assert float((u2 - 1.5 * u.detach()).abs().max() / u.detach().abs().max()) < RTOL_U
+
+
+def test_kappa_recovery_2d_inverse_problem():
+    """BASELINE config 5 pattern at test size: recover per-sample kappa by Adam through the adjoint
+    solve on a 2D mesh (examples/poisson_1d_demo.py:102-110 generalised to a batch)."""
+    mesh = FEMesh.rectangle(32, 32)
+    dev = torch.device("cuda", 0)
+    B = 8
+    gen = torch.Generator().manual_seed(5)
+    k_true = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(dev)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=dev)
+    with torch.no_grad():
+        u_data = DifferentiableFESolver(mesh, k_true)(f)
+    k = torch.ones(B, dtype=T64, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([k], lr=0.1)
+    for _ in range(150):
+        opt.zero_grad()
+        u = DifferentiableFESolver(mesh, k.abs())(f)
+        loss = ((u - u_data) ** 2).mean(dim=1).sum() * 1e4
+        loss.backward()
+        opt.step()
+    assert float((k.detach().abs() - k_true).abs().max()) < 2e-2
