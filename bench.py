@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU (bench contract: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--tol", type=float, default=None, help="override the solver's relative residual tolerance")
+    ap.add_argument("--kappa", choices=["sample", "element"], default="sample",
+                    help="sample: one scalar kappa per sample (the contract workload); element: a log-normal "
+                         "per-element field per sample, exp(0.3 randn) (SURVEY 8(d) C3/C4 variant)")
     return ap.parse_args()
 
 
@@ -62,9 +66,14 @@ def main():
     mesh = FEMesh.rectangle(N, N)
     n = mesh.n_nodes
     gen = torch.Generator().manual_seed(4096 + rank)
-    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=torch.float64)).to(dev).requires_grad_(True)
+    if args.kappa == "sample":
+        kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=torch.float64)).to(dev).requires_grad_(True)
+    else:
+        gdev = torch.Generator(device=dev).manual_seed(2025 + rank)
+        kappa = torch.exp(0.3 * torch.randn(B, mesh.n_elements, generator=gdev, dtype=torch.float64, device=dev))
+        kappa.requires_grad_(True)
     f = torch.ones(B, n, dtype=torch.float64, device=dev)
-    solver = DifferentiableFESolver(mesh, kappa, device=dev)
+    solver = DifferentiableFESolver(mesh, kappa, device=dev, **({"tol": args.tol} if args.tol else {}))
     plan = get_plan(mesh, dev)
 
     iters = []
@@ -104,7 +113,7 @@ def main():
 
     # secondary measurement, same run: V-cycle vectors stored in fp64 instead of fp32
     variant = None
-    if rank == 0 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32"):
+    if rank == 0 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample":
         solver.mg["fp32"] = 0
         step()
         torch.cuda.synchronize(dev)
@@ -123,6 +132,8 @@ def main():
         Bp = padded_batch(B)
         roof = None
         traffic = None
+        roofline_ok = (solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample") or \
+            solver.last_info.path == "ell-pcg"
         st = torch.cuda.current_stream(dev).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -136,7 +147,7 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
 
-        if solver.last_info.path == "lattice-mgpcg":
+        if solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample":
             # dominant kernel: one damped-Jacobi sweep of the V-cycle on the fine level (dia_strip_kernel,
             # M_JACOBI), run on the operator this workload assembles (shared unit matrix + kappa_b scale)
             from diffhe.solver import _Engine, K_SAMPLE
@@ -162,7 +173,7 @@ def main():
             except Exception:
                 traffic = None
             del x, rhs, y, vals
-        elif not plan.is_chain:
+        elif solver.last_info.path == "ell-pcg":
             W = plan.W
             vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
             x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
@@ -174,7 +185,7 @@ def main():
             alg_bytes = (8.0 * W + 16.0) * n * Bp       # read W values + p, write Ap
             kname = "cg_spmv_kernel"
             del vals, x, y, part
-        if not plan.is_chain:
+        if roofline_ok:
             achieved = alg_bytes / dur / 1e9
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -188,7 +199,7 @@ def main():
             bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
             bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
             nodes, elements = mesh.nodes.numpy(), mesh.elements.numpy()
-            kb = float(kappa[0].detach())
+            kb = float(kappa[0].detach()) if args.kappa == "sample" else kappa[0].detach().cpu().numpy()
             tc = time.perf_counter()
             uo, dk, _ = orc.solve_with_adjoint(nodes, elements, bn, bv, kb, np.ones(n), lambda u_: 2 * u_ / B,
                                                sparse=True)
@@ -197,7 +208,9 @@ def main():
                    "sample": f"1 sample of the same workload ({N}x{N}, fwd+adjoint, scipy SuperLU), {tc:.1f} s"}
             ug = u[0].detach().cpu().numpy()
             parity = {"u_rel_err": float(np.max(np.abs(ug - uo)) / np.max(np.abs(uo))),
-                      "dkappa_rel_err": float(abs(float(kappa.grad[0]) - dk.sum()) / abs(dk.sum()))}
+                      "dkappa_rel_err": (float(abs(float(kappa.grad[0]) - dk.sum()) / abs(dk.sum()))
+                                         if args.kappa == "sample" else
+                                         float(np.max(np.abs(kappa.grad[0].cpu().numpy() - dk)) / np.max(np.abs(dk))))}
 
         it = np.array(iters[-args.steps:] if args.steps else iters, dtype=np.float64)
         out = {
@@ -205,8 +218,10 @@ def main():
             "value": round(value, 4), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C4: rectangle({N},{N}), {B} samples/GPU, kappa_b~U(0.5,2) scalar per sample, "
-                                   f"f=1, L=mean_b sum u^2, fwd+adjoint", "mesh": f"{N}x{N}", "batch_per_gpu": B,
+            "config": {"workload": f"C4: rectangle({N},{N}), {B} samples/GPU, "
+                                   + ("kappa_b~U(0.5,2) scalar per sample, " if args.kappa == "sample" else
+                                      "per-element log-normal kappa field per sample, ")
+                                   + "f=1, L=mean_b sum u^2, fwd+adjoint", "mesh": f"{N}x{N}", "batch_per_gpu": B,
                        "global_batch": B * world, "solver": solver.last_info.path, "tol": solver.tol,
                        "multigrid": {k: v for k, v in solver.mg.items() if v is not None},
                        "precision": "fp64 arithmetic, CG vectors, residuals and dots; V-cycle (preconditioner) "

@@ -489,3 +489,25 @@ def test_kappa_recovery_2d_inverse_problem():
         loss.backward()
         opt.step()
     assert float((k.detach().abs() - k_true).abs().max()) < 2e-2
+
+
+def test_neural_pde_against_hip_fem_target():
+    """reference tests/test_neural.py:39-90 with the FEM target coming from the HIP solver:
+    the fem_match loss decreases, the trained net lands within 5 % of the FEM solution, and
+    the Dirichlet mask keeps the boundary at zero."""
+    from diffhe import NeuralPDE
+    torch.manual_seed(42)
+    mesh = FEMesh.line(n_elements=20)
+    model = NeuralPDE(mesh, hidden_dim=32, n_layers=2)
+    losses = model.train_pde(lambda x: torch.ones_like(x), n_epochs=1500, lr=3e-3, mode="fem_match", verbose=False)
+    assert losses[-1] < 0.1 * losses[0]
+    u_nn = model().detach()
+    u_fem = DifferentiableFESolver(mesh)(torch.ones(21, dtype=T64))
+    assert float((u_nn - u_fem).abs().max() / u_fem.abs().max()) < 0.05
+    assert abs(float(u_nn[0])) < 1e-12 and abs(float(u_nn[-1])) < 1e-12
+    # 2D fem_match works here (it raises in the reference, SURVEY section 0 fact 7)
+    mesh2 = FEMesh.rectangle(8, 8)
+    loss2 = PhysicsLoss(mesh2, lambda xy: torch.ones(xy.shape[0], dtype=T64), mode="fem_match")
+    v = loss2(torch.zeros(mesh2.n_nodes, dtype=T64))
+    u2 = DifferentiableFESolver(mesh2)(torch.ones(mesh2.n_nodes, dtype=T64))
+    assert abs(float(v) - float((u2 ** 2).mean())) < 1e-15
