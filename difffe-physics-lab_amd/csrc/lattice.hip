@@ -363,7 +363,8 @@ struct StripGeom {
 
 inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols) {
   StripGeom g{false, 0, 0, 0};
-  if (Bp < kWave || L.W < 4 * kStripCols || L.ny + 1 < 16) return g;
+  // small levels: one wave marching down a strip is latency-bound; the simple kernels win below ~200^2
+  if (Bp < kWave || L.W < 192 || L.ny + 1 < 64) return g;
   g.use = true;
   g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
   const int gy = Bp / kWave;
@@ -415,6 +416,63 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, cons
       out = (double)r[c * Bp + nm.b] + 0.5 * h;
     }
     rc[(i64)I * Bp + nm.b] = (TV)out;
+  }
+}
+
+// Strip variant of the restriction for big levels: a wave owns CW consecutive COARSE columns
+// (2 CW fine columns + one halo column on each side) x 64 samples and marches down the coarse rows,
+// carrying the odd fine row it shares with the next coarse row in registers, so every fine value is
+// loaded ~1.25 times instead of 1.75.
+template <typename TV, int CW>
+__global__ __launch_bounds__(256) void mg_restrict_strip_kernel(Level F, Level C, const TV* __restrict__ r,
+                                                                 TV* __restrict__ rc, int Bp, int ncb, int TR) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * kWave + lane;
+  const int rcn = blockIdx.x / ncb, cb = blockIdx.x - rcn * ncb;
+  const int J0 = (cb * 4 + wave) * CW;        // first coarse column of this wave
+  const int I0 = rcn * TR;                    // first coarse row of this tile
+  const int I1 = (I0 + TR < C.ny + 1) ? I0 + TR : C.ny + 1;
+  if (J0 >= C.W || I0 >= I1) return;
+  constexpr int NW = 2 * CW + 1;              // fine window columns 2*J0 - 1 .. 2*J0 + 2*CW - 1
+  int dq[NW];
+  bool ok[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    int c = 2 * J0 - 1 + q;
+    ok[q] = c >= 0 && c < F.W;
+    c = c < 0 ? 0 : (c > F.W - 1 ? F.W - 1 : c);
+    dq[q] = c;
+  }
+  auto load_row = [&](int fi, double* dst) {
+    const bool rowok = fi >= 0 && fi <= F.ny;
+    const TV* __restrict__ row = r + (i64)(rowok ? fi : 0) * F.W * Bp;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const double v = (double)(row + (i64)dq[q] * Bp)[lb];
+      dst[q] = (rowok && ok[q]) ? v : 0.0;
+    }
+  };
+  double up[NW], mid[NW], dn[NW];
+  load_row(2 * I0 - 1, up);
+  for (int I = I0; I < I1; ++I) {
+    load_row(2 * I, mid);
+    load_row(2 * I + 1, dn);
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+      const int J = J0 + k;
+      if (J < C.W) {
+        const int q = 2 * k + 1;  // window index of fine column 2J
+        // centre + 1/2 (W, E, N, S, NE-of-previous-row, SW-of-next-row)
+        double out = mid[q] + 0.5 * (mid[q - 1] + ((q + 1 < NW) ? mid[q + 1] : 0.0) + up[q] + dn[q] +
+                                      ((q + 1 < NW) ? up[q + 1] : 0.0) + dn[q - 1]);
+        const i64 Ic = (i64)I * C.W + J;
+        if (C.bc[Ic]) out = 0.0;
+        (rc + Ic * Bp)[lb] = (TV)out;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) up[q] = dn[q];
   }
 }
 
@@ -535,8 +593,18 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * kWave + lane;
   double s = 0.0;
-  if (b < Bp)
-    for (int k = wave; k < nblk; k += 16) s += part[(i64)k * Bp + b];
+  if (b < Bp) {  // 4 independent chains keep several loads in flight (fixed order: still deterministic)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = wave;
+    for (; k + 48 < nblk; k += 64) {
+      s0 += part[(i64)k * Bp + b];
+      s1 += part[(i64)(k + 16) * Bp + b];
+      s2 += part[(i64)(k + 32) * Bp + b];
+      s3 += part[(i64)(k + 48) * Bp + b];
+    }
+    for (; k < nblk; k += 16) s0 += part[(i64)k * Bp + b];
+    s = (s0 + s1) + (s2 + s3);
+  }
   lds[wave * kWave + lane] = s;
   __syncthreads();
   if (wave != 0 || b >= Bp) return;
@@ -693,7 +761,19 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     if (l < last) {
       op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
-      LAUNCH(mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
+      if (strip_geom(L, H.Bp).use) {
+        constexpr int CW = 4;
+        const int ncb = (C.W + 4 * CW - 1) / (4 * CW);
+        int nrc = (4096 + ncb * (H.Bp / kWave) - 1) / (ncb * (H.Bp / kWave));
+        if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+        if (nrc < 1) nrc = 1;
+        const int TR = (C.ny + 1 + nrc - 1) / nrc;
+        nrc = (C.ny + 1 + TR - 1) / TR;
+        hipLaunchKernelGGL((mg_restrict_strip_kernel<TV, CW>), dim3(ncb * nrc, H.Bp / kWave), dim3(256), 0, st, L, C,
+                           (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp, ncb, TR);
+      } else {
+        LAUNCH(mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
+      }
       rhs[l + 1] = (const TV*)H.rhs[l + 1];
     }
   }
