@@ -479,10 +479,13 @@ __global__ __launch_bounds__(256) void mg_restrict_strip_kernel(Level F, Level C
 // x += P e  (0 on fine Dirichlet rows)
 template <typename TV>
 __global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, const TV* __restrict__ e,
-                                                              TV* __restrict__ x, int Bp) {
+                                                              TV* __restrict__ x, int Bp, int set = 0) {
   const NodeMap nm = node_map(Bp);
   for (int i = nm.node0; i < F.n; i += nm.stride) {
-    if (F.bc[i]) continue;
+    if (F.bc[i]) {
+      if (set) x[(i64)i * Bp + nm.b] = (TV)0.0;
+      continue;
+    }
     const int fi = i / F.W, fj = i - fi * F.W;
     const int ci = fi >> 1, cj = fj >> 1;
     const i64 c = (i64)ci * C.W + cj;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, c
       v = 0.5 * ((double)e[c * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
     else  // midpoint of the quad diagonal b-d
       v = 0.5 * ((double)e[(c + 1) * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
-    x[(i64)i * Bp + nm.b] = (TV)((double)x[(i64)i * Bp + nm.b] + v);
+    x[(i64)i * Bp + nm.b] = set ? (TV)v : (TV)((double)x[(i64)i * Bp + nm.b] + v);
   }
 }
 
@@ -554,6 +557,33 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
     s += ri * ri;
   }
   STORE_PARTIAL(part, s);
+}
+
+// y += x (TV) ; and the start of the CG from a full-multigrid iterate: x64 = (double) x0
+template <typename TV>
+__global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, TV* __restrict__ y, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    y[o] = (TV)((double)y[o] + (double)x[o]);
+  }
+}
+
+template <typename TV>
+__global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, double* __restrict__ x, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    x[o] = (double)x0[o];
+  }
+}
+
+__global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__ r, float* __restrict__ r32, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    r32[o] = (float)r[o];
+  }
 }
 
 // x += alpha p  (flush of the pending iterate update of the fused CG loop)
@@ -661,6 +691,7 @@ struct Hier {
   int nu, n_coarse;
   // per-level work vectors
   void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
+  void *bF[kMaxLevels], *xF[kMaxLevels];  // full-multigrid start: restricted right-hand sides, iterates
 };
 
 inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
@@ -727,15 +758,15 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
 // z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
 // fine sweep also leaves the partials of rhs0.z there (*rz_blocks of them).
 template <typename TV>
-TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st) {
+TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st, int l0 = 0) {
   const TV* rhs[kMaxLevels];
   TV* cur[kMaxLevels];
-  rhs[0] = rhs0;
+  rhs[l0] = rhs0;  // the cycle runs on levels l0 .. last (l0 > 0: inside full multigrid)
   const int last = H.nl - 1;
-  for (int l = 0; l <= last; ++l) {  // downward leg
+  for (int l = l0; l <= last; ++l) {  // downward leg
     const Level& L = H.lev[l];
     const int sweeps = (l == last) ? H.n_coarse : H.nu;
-    const bool only = (H.nl == 1);  // no coarse level: the cycle is `sweeps` Jacobi sweeps
+    const bool only = (l0 == last);  // no coarser level: the cycle is `sweeps` Jacobi sweeps
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
     int done;
@@ -777,7 +808,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       rhs[l + 1] = (const TV*)H.rhs[l + 1];
     }
   }
-  for (int l = last - 1; l >= 0; --l) {  // upward leg
+  for (int l = last - 1; l >= l0; --l) {  // upward leg
     const Level& L = H.lev[l];
     const Level& C = H.lev[l + 1];
     TV* a = cur[l];
@@ -785,7 +816,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     int s0 = 0;
     const StripGeom g = strip_geom(L, H.Bp);
     if (g.use) {  // prolongate + correct + first post-sweep in one pass
-      const bool lastsweep = (l == 0 && H.nu == 1);
+      const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
       launch_strip<TV, M_JACOBI, false, F_PROLONG, TV>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2, H.omega[H.nu - 1], 0.0,
@@ -797,14 +828,41 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
     }
     for (int s = s0; s < H.nu; ++s) {
-      const bool lastsweep = (l == 0 && s == H.nu - 1);
+      const bool lastsweep = (l == l0 && s == H.nu - 1);
       const int nb = op_jacobi<TV>(H, l, rhs[l], a, b2, H.omega[H.nu - 1 - s], lastsweep ? rz_part : nullptr, st);
       if (lastsweep && rz_blocks) *rz_blocks = nb;
       TV* t = a; a = b2; b2 = t;
     }
     cur[l] = a;
   }
-  return cur[0];
+  return cur[l0];
+}
+
+// Full multigrid start: solve on the coarsest level, then per level interpolate, take the residual
+// and apply one V-cycle.  Gives the CG an iterate whose error is already smooth (about 3-4 CG
+// iterations ahead of a zero guess) for ~0.8 of an iteration.  b0 = right-hand side in TV storage.
+template <typename TV>
+TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
+  const int last = H.nl - 1;
+  const TV* bl[kMaxLevels];
+  bl[0] = b0;
+  for (int l = 0; l < last; ++l) {
+    LAUNCH(mg_restrict_kernel<TV>, H.lev[l + 1].n, H.lev[l], H.lev[l + 1], bl[l], (TV*)H.bF[l + 1], H.Bp);
+    bl[l + 1] = (const TV*)H.bF[l + 1];
+  }
+  {  // coarsest level: the V-cycle from `last` is n_coarse Jacobi sweeps
+    TV* e = vcycle<TV>(H, bl[last], nullptr, nullptr, st, last);
+    hipMemcpyAsync(H.xF[last], e, (size_t)H.lev[last].n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st);
+  }
+  for (int l = last - 1; l >= 0; --l) {
+    const Level& L = H.lev[l];
+    TV* x = (TV*)H.xF[l];
+    LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], (const TV*)H.xF[l + 1], x, H.Bp, 1);
+    op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
+    TV* e = vcycle<TV>(H, (const TV*)H.rhs[l], nullptr, nullptr, st, l);
+    LAUNCH(mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
+  }
+  return (TV*)H.xF[0];
 }
 
 }  // namespace
@@ -847,7 +905,9 @@ static long long carve(Hier& H, double* work, bool fp32) {
     H.xa[l] = take(nb);
     H.xb[l] = take(nb);
     H.res[l] = take(nb);
-    H.rhs[l] = (l > 0 || fp32) ? take(nb) : nullptr;  // level 0, fp32: the fp32 copy of the CG residual
+    H.rhs[l] = take(nb);  // level 0: fp32 copy of the CG residual / FMG residual
+    H.bF[l] = l > 0 ? take(nb) : nullptr;
+    H.xF[l] = take(nb);
   }
   return off;
 }
@@ -875,7 +935,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const int n = L0.n;
   const long long nb = (long long)n * Bp;
   const int nblk = lgrid(n, Bp).x;
-  const bool f32 = precond_fp32 != 0;
+  const bool f32 = (precond_fp32 & 1) != 0;
+  const bool use_fmg = (precond_fp32 & 2) != 0 && H.nl > 1;
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;
@@ -928,6 +989,17 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       nba = op_apply_dot(H, p, Ap, partA, st);
     }
   };
+  if (use_fmg) {  // x0 = FMG(b); r = b - A x0
+    if (f32) {
+      const float* x0 = fmg_start<float>(H, (const float*)r32, st);
+      LAUNCH(pcg_setx_kernel<float>, n, x0, x, n, Bp);
+    } else {
+      const double* x0 = fmg_start<double>(H, b, st);
+      LAUNCH(pcg_setx_kernel<double>, n, x0, x, n, Bp);
+    }
+    op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
+    if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, r32, n, Bp);
+  }
   precondition(1);
   rc = diffhe::check_launch();
   if (rc) return rc;

@@ -228,7 +228,7 @@ class _Engine:
         om = (ctypes.c_double * len(omegas))(*omegas)
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               self.max_iter, len(omegas), mg["n_coarse"], om,
-                                              int(mg.get("fp32", 0)), _hip.ptr(work),
+                                              int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1), _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
                                               _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
@@ -397,7 +397,8 @@ class DifferentiableFESolver(nn.Module):
         self.method = method      # "ell" forces the general path on lattice meshes
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
-        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1)
+        # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)
+        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1, fmg=1)
         for item in filter(None, os.environ.get("DIFFHE_MG", "").split(",")):   # e.g. "nu=1,omega=0.85"
             key, val = item.split("=")
             if key == "omegas":

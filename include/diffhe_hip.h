@@ -171,8 +171,9 @@ typedef struct diffhe_mg_level {
  *   levels   HOST array of n_levels descriptors (device pointers inside)
  *   Bv       Bp (matrix per sample) or 1 (shared); scale (Bp) or NULL: K_b = scale[b]*K on
  *            the free rows (one scalar kappa per sample, solver.py:88,139)
- *   precond_fp32  != 0: the V-cycle stores its vectors in fp32 (arithmetic stays fp64 in
- *            registers; the outer CG, its residual and all dot products are fp64)
+ *   precond_fp32  bit 0: the V-cycle stores its vectors in fp32 (arithmetic stays fp64 in
+ *            registers; the outer CG, its residual and all dot products are fp64);
+ *            bit 1: start the CG from a full-multigrid iterate instead of 0
  *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */
