@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--tol", type=float, default=None, help="override the solver's relative residual tolerance")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--all-on-device", type=int, default=None,
+                    help="rehearsal only: put every rank on this device index (needs --backend gloo)")
     ap.add_argument("--kappa", choices=["sample", "element"], default="sample",
                     help="sample: one scalar kappa per sample (the contract workload); element: a log-normal "
                          "per-element field per sample, exp(0.3 randn) (SURVEY 8(d) C3/C4 variant)")
@@ -54,10 +57,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.all_on_device is not None:
+        local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from diffhe import FEMesh, DifferentiableFESolver, _hip
     from diffhe.plan import get_plan, padded_batch
@@ -231,6 +239,7 @@ def main():
                              "max_relres_fwd": float(it[:, 2].max()), "max_relres_adj": float(it[:, 3].max()),
                              "not_converged": int(it[:, 4].max())},
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity, "variants": variant,
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -688,7 +688,7 @@ struct Hier {
   int nl, Bv, Bp;
   const double* scale;
   double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
-  int nu, n_coarse;
+  int nu, n_coarse, fmg_coarse_cycles;
   // per-level work vectors
   void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
   void *bF[kMaxLevels], *xF[kMaxLevels];  // full-multigrid start: restricted right-hand sides, iterates
@@ -858,9 +858,12 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
     const Level& L = H.lev[l];
     TV* x = (TV*)H.xF[l];
     LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], (const TV*)H.xF[l + 1], x, H.Bp, 1);
-    op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
-    TV* e = vcycle<TV>(H, (const TV*)H.rhs[l], nullptr, nullptr, st, l);
-    LAUNCH(mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
+    const int cycles = (l == 0) ? 1 : H.fmg_coarse_cycles;  // extra cycles on the cheap coarse levels
+    for (int c = 0; c < cycles; ++c) {
+      op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
+      TV* e = vcycle<TV>(H, (const TV*)H.rhs[l], nullptr, nullptr, st, l);
+      LAUNCH(mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
+    }
   }
   return (TV*)H.xF[0];
 }
@@ -886,6 +889,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     L.v = s.vals; L.bc = s.is_bc;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
+  H.fmg_coarse_cycles = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
 }
@@ -937,6 +941,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const int nblk = lgrid(n, Bp).x;
   const bool f32 = (precond_fp32 & 1) != 0;
   const bool use_fmg = (precond_fp32 & 2) != 0 && H.nl > 1;
+  H.fmg_coarse_cycles = 1 + ((precond_fp32 >> 2) & 3);
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;

@@ -228,7 +228,8 @@ class _Engine:
         om = (ctypes.c_double * len(omegas))(*omegas)
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               self.max_iter, len(omegas), mg["n_coarse"], om,
-                                              int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1), _hip.ptr(work),
+                                              int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
+                                              | ((int(mg.get("fmg_cycles", 1)) - 1) << 2), _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
                                               _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
@@ -407,6 +408,8 @@ class DifferentiableFESolver(nn.Module):
                 self.mg[key] = float(val) if key == "omega" else int(val)
         self.mg.update(mg or {})
         self._device = device
+        if os.environ.get("DIFFHE_TOL"):
+            tol = float(os.environ["DIFFHE_TOL"])
         self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
         self.last_info = SolveInfo()
 
