@@ -511,3 +511,51 @@ def test_neural_pde_against_hip_fem_target():
     v = loss2(torch.zeros(mesh2.n_nodes, dtype=T64))
     u2 = DifferentiableFESolver(mesh2)(torch.ones(mesh2.n_nodes, dtype=T64))
     assert abs(float(v) - float((u2 ** 2).mean())) < 1e-15
+
+
+@pytest.mark.parametrize("N,B", [(256, 100), (192, 640)])
+def test_lattice_ragged_and_large_batches(N, B):
+    """Batch sizes that are not a multiple of the wave (padding samples carry kappa = 1, f = 0 and
+    must stay inert) and batches larger than one sample-chunk row of the grid, on the strip /
+    fused / full-multigrid path; checked against the exact DST solution and the adjoint identity."""
+    mesh = FEMesh.rectangle(N, N)
+    n = mesh.n_nodes
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(7)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(dev).requires_grad_(True)
+    f = (1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)).to(dev)
+    solver = DifferentiableFESolver(mesh, kappa)
+    u = solver(f)
+    assert u.shape == (B, n) and solver.last_info.not_converged == 0
+    L = (u ** 2).sum(dim=1)
+    L.sum().backward()
+    ref = -2.0 * L.detach() / kappa.detach()
+    assert float(((kappa.grad - ref).abs() / ref.abs()).max()) < RTOL_GRAD
+    nodes, el, bn, bv = arrays(mesh)
+    for b in (0, B // 2, B - 1):
+        F = orc.load_vector(nodes, el, f[b].cpu().numpy()).reshape(N + 1, N + 1)[1:-1, 1:-1]
+        ue = np.zeros((N + 1, N + 1))
+        ue[1:-1, 1:-1] = _dst_solve_unit_square(N, float(kappa[b]), F)
+        assert rel_err(u[b].detach().cpu().numpy(), ue.ravel()) < RTOL_U
+
+
+def test_empty_and_degenerate_inputs():
+    """Edge cases: zero forcing with non-zero Dirichlet data, a degenerate (zero-area) triangle is
+    skipped (reference solver.py:120-121), wrong sizes raise."""
+    mesh = FEMesh.rectangle(6, 6, bc_value=0.75)
+    u = DifferentiableFESolver(mesh)(torch.zeros(mesh.n_nodes, dtype=T64))
+    assert float((u - 0.75).abs().max()) < 1e-12                  # harmonic extension of a constant
+    with pytest.raises(ValueError):
+        DifferentiableFESolver(mesh)(torch.zeros(mesh.n_nodes + 1, dtype=T64))
+    with pytest.raises(ValueError):
+        DifferentiableFESolver(mesh, torch.ones(3, dtype=T64))(torch.zeros(5, mesh.n_nodes, dtype=T64))
+    # unstructured mesh with one degenerate triangle appended: same solution as without it
+    base = FEMesh.rectangle(4, 4)
+    nodes, el, bn, bv = arrays(base)
+    perm = np.random.default_rng(1).permutation(len(el))
+    el2 = np.vstack([el[perm], [[0, 1, 1]]])                       # repeated vertex -> area 0
+    mesh2 = FEMesh(nodes=base.nodes, elements=torch.from_numpy(el2), dirichlet_nodes=dict(base.dirichlet_nodes))
+    f = torch.from_numpy(1 + 0.3 * np.random.default_rng(2).standard_normal(base.n_nodes))
+    u2 = DifferentiableFESolver(mesh2, 1.3)(f)
+    uo = orc.solve(nodes, el, bn, bv, 1.3, f.numpy())
+    assert rel_err(u2.numpy(), uo) < RTOL_U
