@@ -24,6 +24,7 @@ typedef long long i64;
 struct Level {
   int nx, ny, n, W, nd;
   const double* v;          // (nd, n, Bv)
+  const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels (Bv == Bp)
   const unsigned char* bc;  // (n)
 };
 
@@ -153,7 +154,8 @@ struct Extra {
   const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there)
 };
 
-template <typename TV, typename TA, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW, bool TAIL>
+template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
+          bool TAIL>
 __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV* __restrict__ src,
                                              const TV* __restrict__ bvec, TV* __restrict__ out, double omega,
                                              double omega_in, const Extra& ex, int Bp, int b, int c0w, int r0,
@@ -184,10 +186,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   // D_k[i] lives at V[(k*n + i)*Bv + vb]; for k >= 1 a negative i (>= -n) still indexes valid,
   // finite memory (the previous diagonal) and is only ever multiplied by a window value of 0.
   const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
-  const double* __restrict__ p0 = L.v + i0 * Bv;
-  const double* __restrict__ p1 = p0 + n * Bv;
-  const double* __restrict__ p2 = p1 + n * Bv;
-  const double* __restrict__ p3 = p2 + n * Bv;
+  const TM* __restrict__ p0 = (sizeof(TM) == 4 ? (const TM*)L.v32 : (const TM*)L.v) + i0 * Bv;
+  const TM* __restrict__ p1 = p0 + n * Bv;
+  const TM* __restrict__ p2 = p1 + n * Bv;
+  const TM* __restrict__ p3 = p2 + n * Bv;
   const TV* __restrict__ px = src + i0 * Bp;
   const TV* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
   TV* __restrict__ po = out ? out + i0 * Bp : nullptr;
@@ -204,7 +206,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 
   // `row` is the grid row being loaded; xrow / d0row point at (row, c0w); roff = offset of that
   // row from the current one in vector elements
-  auto load_window = [&](int row, i64 roff, const TV* __restrict__ xrow, const double* __restrict__ d0row,
+  auto load_window = [&](int row, i64 roff, const TV* __restrict__ xrow, const TM* __restrict__ d0row,
                          double* dst) {
     double ce[RW / 2 + 2], ce2[RW / 2 + 2];
     if (FUSE == F_PROLONG) {  // coarse values around this strip: coarse columns c0w/2 - 1 + j
@@ -227,7 +229,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       } else {
         v = (double)(xrow + (i64)dq[q] * Bp)[lb];
       }
-      if (XFROMB) v = omega_in * v / (sb * (d0row + (i64)dq[q] * Bv)[lv]);
+      if (XFROMB) v = omega_in * v / (sb * (double)(d0row + (i64)dq[q] * Bv)[lv]);
       if (FUSE == F_PROLONG) {
         double corr;  // c0w is even: window column q has the parity of q + 1
         if (q & 1)
@@ -248,9 +250,9 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   if (r0 > 0) load_window(r0 - 1, -rowX, px - rowX, p0 - rowV, xm);
   load_window(r0, 0, px, p0, xc);
 #pragma unroll
-  for (int k = 0; k < RW; ++k) n2p[k] = (p2 - rowV + (i64)dq[k + 1] * Bv)[lv];
+  for (int k = 0; k < RW; ++k) n2p[k] = (double)(p2 - rowV + (i64)dq[k + 1] * Bv)[lv];
 #pragma unroll
-  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (p3 - rowV + (i64)dq[k + 1] * Bv)[lv] : 0.0;
+  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (double)(p3 - rowV + (i64)dq[k + 1] * Bv)[lv] : 0.0;
 
   for (int row = r0; row < r1; ++row) {
     if (row + 1 < nyp) {
@@ -262,16 +264,16 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     double d0[RW], e1[RW + 1], n2c[RW], d3c[RW + 1];
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
-      d0[k] = (p0 + (i64)dq[k + 1] * Bv)[lv];
-      n2c[k] = (p2 + (i64)dq[k + 1] * Bv)[lv];
+      d0[k] = (double)(p0 + (i64)dq[k + 1] * Bv)[lv];
+      n2c[k] = (double)(p2 + (i64)dq[k + 1] * Bv)[lv];
     }
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) {
       // east coupling of column c0w-1+k; column -1 reads the element before the row (valid
       // memory, multiplied by a zero window value)
       const int dc = TAIL ? dq[k] : k - 1;
-      e1[k] = (p1 + (i64)dc * Bv)[lv];
-      d3c[k] = (ND == 4) ? (p3 + (i64)dq[k + 1] * Bv)[lv] : 0.0;
+      e1[k] = (double)(p1 + (i64)dc * Bv)[lv];
+      d3c[k] = (ND == 4) ? (double)(p3 + (i64)dq[k + 1] * Bv)[lv] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -321,7 +323,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   return s;
 }
 
-template <typename TV, typename TA, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW>
+template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW>
 __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
                                                          const TV* __restrict__ xin, const TV* __restrict__ bvec,
                                                          TV* __restrict__ out, double omega, double omega_in,
@@ -341,10 +343,10 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
   double s = 0.0;
   if (c0w < L.W && r0 < r1) {
     if (c0w + RW + 1 > L.W)
-      s = strip_body<TV, TA, MODE, FUSE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
+      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
                                                                        c0w, r0, r1);
     else
-      s = strip_body<TV, TA, MODE, FUSE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
+      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
                                                                         c0w, r0, r1);
   }
   if (part) {
@@ -384,13 +386,15 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
                   double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st,
                   const Extra& ex = Extra{}) {
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
-#define STRIP(ND_, SH_)                                                                                            \
-  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, MODE, FUSE, ND_, SH_, XFROMB, RW>), grid, dim3(256), 0, st, L, \
+#define STRIP(ND_, SH_, TM_)                                                                                       \
+  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW>), grid, dim3(256), 0, st, L,   \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
+  // per-sample matrices inside the fp32 V-cycle read the fp32 copy of the coefficients
+  const bool m32 = (sizeof(TV) == 4) && Bv != 1 && L.v32 != nullptr;
   if (L.nd == 3) {
-    if (Bv == 1) STRIP(3, true); else STRIP(3, false);
+    if (Bv == 1) STRIP(3, true, double); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
   } else {
-    if (Bv == 1) STRIP(4, true); else STRIP(4, false);
+    if (Bv == 1) STRIP(4, true, double); else if (m32) STRIP(4, false, float); else STRIP(4, false, double);
   }
 #undef STRIP
 }
@@ -886,7 +890,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.bc = s.is_bc;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.fmg_coarse_cycles = 1;

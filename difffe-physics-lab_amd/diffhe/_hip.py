@@ -17,7 +17,7 @@ _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
 
 class MgLevel(C.Structure):
     """struct diffhe_mg_level (include/diffhe_hip.h)."""
-    _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P)]
+    _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P), ("vals32", _P)]
 
 
 _LV = C.POINTER(MgLevel)

@@ -208,16 +208,17 @@ class _Engine:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def lattice_levels(self, vals):
+    def lattice_levels(self, vals, vals32=None):
         arr = (_hip.MgLevel * len(vals))()
         for i, (lev, v) in enumerate(zip(self.p.levels, vals)):
             arr[i].nx, arr[i].ny, arr[i].nd, arr[i].reserved = lev.nx, lev.ny, lev.nd, 0
             arr[i].vals, arr[i].is_bc = v.data_ptr(), lev.is_bc.data_ptr()
+            arr[i].vals32 = vals32[i].data_ptr() if vals32 is not None and vals32[i] is not None else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None):
         p, L = self.p, self.L
-        arr = self.lattice_levels(vals)
+        arr = self.lattice_levels(vals, vals32)
         nl = len(vals)
         x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
         work = torch.empty(L.diffhe_lattice_pcg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
@@ -288,11 +289,14 @@ class _FESolve(torch.autograd.Function):
             vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
             f_nm = eng.to_node_major(f_dev, B, Bp, n)
             rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale)
-            x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg)
+            # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
+            vals32 = [v.float() for v in vals] if (Bv != 1 and solver.mg.get("fp32")) else None
+            x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg, vals32)
             info.iterations, info.not_converged = its, bad
             info.max_relres = float(relres[:B].max())
             u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
             ctx.saved = (vals, x, Bp, Bv, scale)
+            ctx.vals32 = vals32
         else:
             info.path = "ell-pcg"
             Bp = padded_batch(B)
@@ -337,7 +341,7 @@ class _FESolve(torch.autograd.Function):
             vals, x, Bp, Bv, scale = ctx.saved
             rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
             if ctx.path == "lattice-mgpcg":
-                lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.solver.mg)
+                lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.solver.mg, ctx.vals32)
             else:
                 lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
             info.adj_iterations = its

@@ -161,6 +161,8 @@ typedef struct diffhe_mg_level {
   int reserved;
   const double* vals;          /* (nd, n, Bv) */
   const unsigned char* is_bc;  /* (n) */
+  const float* vals32;         /* optional fp32 copy of vals (NULL = none): read by the fp32-stored
+                                  V-cycle when Bv == Bp; the outer CG always applies the fp64 values */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
