@@ -121,7 +121,7 @@ def main():
 
     # secondary measurement, same run: V-cycle vectors stored in fp64 instead of fp32
     variant = None
-    if rank == 0 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample":
+    if world == 1 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample":
         solver.mg["fp32"] = 0
         step()
         torch.cuda.synchronize(dev)

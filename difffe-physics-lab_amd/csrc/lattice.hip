@@ -152,6 +152,8 @@ struct Extra {
   int first;                // F_PUPD: first iteration (p = z, nothing pending)
   int cW;                   // F_PROLONG: row width of the coarse level
   const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there)
+  const double* dotv;       // M_APPLY, F_NONE: dot (A x + addv) against this vector instead of x
+  const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
@@ -286,8 +288,13 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       const i64 o = (i64)k * Bp;
       if (MODE == M_APPLY) {
         const double y = sb * acc;
-        (po + o)[lb] = (TV)y;
-        s += y * xc[q];
+        if (po) (po + o)[lb] = (TV)y;
+        if (FUSE == F_NONE && ex.dotv) {  // bilinear form lam^T (A x + add): dL/dkappa of a factored operator
+          const i64 ig = (i64)row * W + c0w + k;
+          s += (y + (ex.addv ? ex.addv[ig] : 0.0)) * (ex.dotv + ig * Bp)[lb];
+        } else {
+          s += y * xc[q];
+        }
         if (FUSE == F_PUPD) {  // store the new direction; apply the pending x += alpha_prev * p_old
           (ppo + o)[lb] = xc[q];
           if (!ex.first) (pxx + o)[lb] += alpha_prev * (ppi + o)[lb];
@@ -618,7 +625,7 @@ struct PcgScalars {
   double *rz, *alpha, *beta, *bb, *tol2;
   int *active, *iters, *n_active;
 };
-enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5 };
+enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6 };
 
 // 1024 threads: lanes over samples, 16 waves over slices of the partial list (fixed order)
 __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const double* __restrict__ part, int nblk, int Bp,
@@ -678,6 +685,9 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
       } else {
         S.beta[b] = 0.0;
       }
+      break;
+    case S_SUM:  // plain per-sample total
+      relres[b] = a;
       break;
     default:  // S_RELRES: a = |b - A x|^2
       relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
@@ -1050,6 +1060,28 @@ extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const 
   int rc = fill_hier(H, level, 1, Bv, Bp, scale, &w1, 1, 1);
   if (rc) return rc;
   op_apply_dot(H, x, y, part, (hipStream_t)stream);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
+                                       const double* lam, const double* add, double* part, double* out, int Bp,
+                                       void* stream) {
+  if (!x || !lam || !part || !out) return DIFFHE_E_BADARG;
+  Hier H;
+  const double w1 = 0.8;
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, &w1, 1, 1);
+  if (rc) return rc;
+  const StripGeom g = strip_geom(H.lev[0], Bp);
+  if (!g.use) return DIFFHE_E_TOOBIG;  // small problems: use diffhe_p1_grad_kappa
+  hipStream_t st = (hipStream_t)stream;
+  Extra ex{};
+  ex.dotv = lam;
+  ex.addv = add;
+  launch_strip<double, M_APPLY, false>(H.lev[0], Bv, scale, x, (const double*)nullptr, (double*)nullptr, 0.0, 0.0, part,
+                                       Bp, g, st, ex);
+  PcgScalars S{};
+  hipLaunchKernelGGL(pcg_scalar_kernel, dim3((Bp + 63) / 64), dim3(1024), 0, st, (int)S_SUM, (const double*)part,
+                     g.ncb * g.nrc, Bp, 0.0, S, out);
   return diffhe::check_launch();
 }
 

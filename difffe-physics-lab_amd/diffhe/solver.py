@@ -236,6 +236,20 @@ class _Engine:
         st = p.pinned_status
         return x, int(st[0]), int(st[1]), relres
 
+    def grad_kappa_factored(self, vals, lift, lam, x, Bp):
+        """dL/dkappa_b = -lam^T K_1 u for a batch-shared (factored) lattice operator in one strip pass:
+        lam^T (A_1 x + K_1[free,bc] g).  Returns None below the strip-kernel threshold."""
+        p, L = self.p, self.L
+        arr = self.lattice_levels(vals[:1])
+        part = torch.empty(L.diffhe_lattice_blocks(p.n, Bp) * Bp, dtype=torch.float64, device=p.device)
+        out = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        rc = L.diffhe_lattice_bilinear(arr, 1, None, _hip.ptr(x), _hip.ptr(lam), _hip.ptr(lift), _hip.ptr(part),
+                                       _hip.ptr(out), Bp, _stream(p.device))
+        if rc == -3:
+            return None
+        _hip.check(rc, "diffhe_lattice_bilinear")
+        return -out
+
     def grad_kappa(self, lam, x, Bp, want_elem):
         p, L = self.p, self.L
         nblk = L.diffhe_grad_kappa_blocks(p.m, Bp)
@@ -268,6 +282,7 @@ class _FESolve(torch.autograd.Function):
         ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
         ctx.mode, ctx.B, ctx.batched_f, ctx.out_device = mode, B, batched, out_device
         ctx.kappa_shape, ctx.kappa_device = kappa.shape, kappa.device
+        ctx.kappa_value = kappa.detach().to(plan.device, torch.float64).reshape(-1)[0] if mode == K_SCALAR else None
 
         if plan.is_chain:
             info.path = "chain1d-scan"
@@ -297,6 +312,7 @@ class _FESolve(torch.autograd.Function):
             u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
             ctx.saved = (vals, x, Bp, Bv, scale)
             ctx.vals32 = vals32
+            ctx.lift = lift if Bv == 1 else None
         else:
             info.path = "ell-pcg"
             Bp = padded_batch(B)
@@ -348,7 +364,13 @@ class _FESolve(torch.autograd.Function):
             info.adj_max_relres = float(relres[:B].max())
             info.not_converged += bad
             want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
-            dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e) if need_k else (None, None)
+            dk_nm = dk_sum = None
+            if need_k and ctx.path == "lattice-mgpcg" and mode in (K_SCALAR, K_SAMPLE):
+                dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
+                if dk_sum is not None and mode == K_SCALAR:
+                    dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
+            if need_k and dk_sum is None:
+                dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e)
             dk_sample = dk_sum[:B] if need_k else None
             dk_elem = None
             if need_k and want_e:

@@ -192,6 +192,13 @@ int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* sca
                          double* part, int Bp, void* stream);
 int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,
                           const double* xin, double* xout, double omega, int Bp, void* stream);
+/* out[b] = sum_i lam[i,b] * ((A x)[i,b] + add[i]): the dL/dkappa contraction of a batch-FACTORED
+ * operator (K_b = kappa_b K_1: -lam^T K_1 u with u = x + g, add = K_1[free,bc] g), one pass over
+ * x and lam instead of the element loop.  Returns DIFFHE_E_TOOBIG when the mesh/batch is below the
+ * strip-kernel threshold (callers then use diffhe_p1_grad_kappa).  add (n) may be NULL;
+ * part: diffhe_lattice_blocks(n, Bp) * Bp doubles; out (Bp). */
+int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
+                            const double* lam, const double* add, double* part, double* out, int Bp, void* stream);
 /* kappa_coarse[E] = mean of the 4 children of coarse triangle E; arrays (m, Bv). */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
                                   int Bv, void* stream);
