@@ -325,8 +325,18 @@ __global__ __launch_bounds__(256) void residual_kernel(const double* __restrict_
 __device__ inline double sum_partials(const double* __restrict__ part, int nblk, int Bp, int b, double* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double s = 0.0;
-  if (b < Bp)
-    for (int k = wave; k < nblk; k += 4) s += part[(i64)k * Bp + b];
+  if (b < Bp) {  // 4 independent chains keep several loads in flight (fixed order: still deterministic)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = wave;
+    for (; k + 12 < nblk; k += 16) {
+      s0 += part[(i64)k * Bp + b];
+      s1 += part[(i64)(k + 4) * Bp + b];
+      s2 += part[(i64)(k + 8) * Bp + b];
+      s3 += part[(i64)(k + 12) * Bp + b];
+    }
+    for (; k < nblk; k += 4) s0 += part[(i64)k * Bp + b];
+    s = (s0 + s1) + (s2 + s3);
+  }
   lds[wave * kWave + lane] = s;
   __syncthreads();
   const double t = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
