@@ -16,9 +16,12 @@ Extensions over the reference (which has no batch dimension, solver.py:54):
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
+import types
+import weakref
 from dataclasses import dataclass
-from typing import Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -262,137 +265,208 @@ class _Engine:
         return dk_e, dk_sum
 
 
-class _FESolve(torch.autograd.Function):
-    """u = K(kappa)^{-1} F(f) with Dirichlet elimination; explicit adjoint."""
+def _solve_forward(solver, kappa, f):
+    """u = K(kappa)^{-1} F(f) with Dirichlet elimination.  Returns (u, state); `state` carries what
+    the explicit adjoint needs (assembled operators, the eliminated solution, layout facts)."""
+    ctx = types.SimpleNamespace()
+    plan: SolvePlan = solver._plan()
+    eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
+    out_device = f.device
+    batched = f.dim() == 2
+    m, n = plan.m, plan.n
+    B_f = f.shape[0] if batched else None
+    mode, B_k = _kappa_mode(kappa, m, B_f)
+    B = B_f if B_f is not None else (B_k if B_k is not None else 1)
+    if B_k is not None and B_k != B:
+        raise ValueError(f"kappa batch {B_k} does not match f batch {B}")
+    f_dev = f.detach().to(plan.device, torch.float64).contiguous()
+    info = SolveInfo()
+    ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
+    ctx.mode, ctx.B, ctx.batched_f, ctx.out_device = mode, B, batched, out_device
+    ctx.kappa_shape, ctx.kappa_device = kappa.shape, kappa.device
+    ctx.kappa_value = kappa.detach().to(plan.device, torch.float64).reshape(-1)[0] if mode == K_SCALAR else None
 
-    @staticmethod
-    def forward(ctx, kappa, f, solver):
-        plan: SolvePlan = solver._plan()
-        eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
-        out_device = f.device
-        batched = f.dim() == 2
-        m, n = plan.m, plan.n
-        B_f = f.shape[0] if batched else None
-        mode, B_k = _kappa_mode(kappa, m, B_f)
-        B = B_f if B_f is not None else (B_k if B_k is not None else 1)
-        if B_k is not None and B_k != B:
-            raise ValueError(f"kappa batch {B_k} does not match f batch {B}")
-        f_dev = f.detach().to(plan.device, torch.float64).contiguous()
-        info = SolveInfo()
-        ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
-        ctx.mode, ctx.B, ctx.batched_f, ctx.out_device = mode, B, batched, out_device
-        ctx.kappa_shape, ctx.kappa_device = kappa.shape, kappa.device
-        ctx.kappa_value = kappa.detach().to(plan.device, torch.float64).reshape(-1)[0] if mode == K_SCALAR else None
+    if plan.is_chain:
+        info.path = "chain1d-scan"
+        L = eng.L
+        kdev = kappa.detach().to(plan.device, torch.float64).contiguous()
+        ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
+        u = torch.empty((B, n), dtype=torch.float64, device=plan.device)
+        stage = None
+        if 16 * (n - 1) > 160 * 1024 - 2048:
+            stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+        _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
+                                          n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
+                                          _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
+                   "diffhe_chain1d_solve")
+        ctx.saved = (kdev, ksb, kse, u)
+    elif plan.is_lattice and solver.method != "ell":
+        info.path = "lattice-mgpcg"
+        Bp = padded_batch(B)
+        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
+        f_nm = eng.to_node_major(f_dev, B, Bp, n)
+        rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale)
+        # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
+        vals32 = [v.float() for v in vals] if (Bv != 1 and solver.mg.get("fp32")) else None
+        x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg, vals32)
+        info.iterations, info.not_converged = its, bad
+        info.max_relres = float(relres[:B].max())
+        u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+        ctx.saved = (vals, x, Bp, Bv, scale)
+        ctx.vals32 = vals32
+        ctx.lift = lift if Bv == 1 else None
+    else:
+        info.path = "ell-pcg"
+        Bp = padded_batch(B)
+        kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
+        vals, lift = eng.assemble(kdev, kse, ksb, Bv)
+        f_nm = eng.to_node_major(f_dev, B, Bp, n)
+        rhs = eng.load_vector(f_nm, lift, Bv, Bp)
+        x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+        info.iterations, info.not_converged = its, bad
+        info.max_relres = float(relres[:B].max())
+        u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+        ctx.saved = (vals, x, Bp, Bv, None)
+    solver.last_info = info
+    ctx.path = info.path
+    out = u if batched or B > 1 else u[0]
+    return out.to(out_device), ctx
 
-        if plan.is_chain:
-            info.path = "chain1d-scan"
-            L = eng.L
-            kdev = kappa.detach().to(plan.device, torch.float64).contiguous()
-            ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
-            u = torch.empty((B, n), dtype=torch.float64, device=plan.device)
-            stage = None
-            if 16 * (n - 1) > 160 * 1024 - 2048:
-                stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
-            _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
-                                              n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
-                                              _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
-                       "diffhe_chain1d_solve")
-            ctx.saved = (kdev, ksb, kse, u)
-        elif plan.is_lattice and solver.method != "ell":
-            info.path = "lattice-mgpcg"
-            Bp = padded_batch(B)
-            vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
-            f_nm = eng.to_node_major(f_dev, B, Bp, n)
-            rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale)
-            # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
-            vals32 = [v.float() for v in vals] if (Bv != 1 and solver.mg.get("fp32")) else None
-            x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg, vals32)
-            info.iterations, info.not_converged = its, bad
-            info.max_relres = float(relres[:B].max())
-            u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
-            ctx.saved = (vals, x, Bp, Bv, scale)
-            ctx.vals32 = vals32
-            ctx.lift = lift if Bv == 1 else None
+
+def _solve_backward(ctx, gbar, need_k, need_f):
+    """Explicit adjoint: lambda = K_free^{-1} gbar_free with the saved operators,
+    dL/dkappa = -lambda^T k0 u, dL/df = M^T lambda.  Returns (grad_kappa | None, grad_f | None)."""
+    plan, eng, mode, B = ctx.plan, ctx.eng, ctx.mode, ctx.B
+    m, n = plan.m, plan.n
+    g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
+    info = ctx.solver.last_info
+    if plan.is_chain:
+        kdev, ksb, kse, u = ctx.saved
+        L = eng.L
+        df = torch.empty((B, n), dtype=torch.float64, device=plan.device)
+        want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
+        dk_e = torch.empty((B, m), dtype=torch.float64, device=plan.device) if want_e else None
+        part = torch.empty((B, plan.n_seg), dtype=torch.float64, device=plan.device)
+        stage = None
+        if 16 * (n - 1) > 160 * 1024 - 2048:
+            stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+        _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(g_dev), n,
+                                            _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(df), n,
+                                            _hip.ptr(dk_e), m, _hip.ptr(part), n, B, _hip.ptr(stage),
+                                            _stream(plan.device)), "diffhe_chain1d_adjoint")
+        dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
+        dk_elem = dk_e
+    else:
+        vals, x, Bp, Bv, scale = ctx.saved
+        rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
+        if ctx.path == "lattice-mgpcg":
+            lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.solver.mg, ctx.vals32)
         else:
-            info.path = "ell-pcg"
-            Bp = padded_batch(B)
-            kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
-            vals, lift = eng.assemble(kdev, kse, ksb, Bv)
-            f_nm = eng.to_node_major(f_dev, B, Bp, n)
-            rhs = eng.load_vector(f_nm, lift, Bv, Bp)
-            x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
-            info.iterations, info.not_converged = its, bad
-            info.max_relres = float(relres[:B].max())
-            u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
-            ctx.saved = (vals, x, Bp, Bv, None)
-        solver.last_info = info
-        ctx.path = info.path
-        out = u if batched or B > 1 else u[0]
-        return out.to(out_device)
+            lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+        info.adj_iterations = its
+        info.adj_max_relres = float(relres[:B].max())
+        info.not_converged += bad
+        want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
+        dk_nm = dk_sum = None
+        if need_k and ctx.path == "lattice-mgpcg" and mode in (K_SCALAR, K_SAMPLE):
+            dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
+            if dk_sum is not None and mode == K_SCALAR:
+                dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
+        if need_k and dk_sum is None:
+            dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e)
+        dk_sample = dk_sum[:B] if need_k else None
+        dk_elem = None
+        if need_k and want_e:
+            dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
+        df = eng.to_sample_major(eng.apply_M(lam, Bp), B, Bp, n) if need_f else None
 
-    @staticmethod
-    def backward(ctx, gbar):
-        plan, eng, mode, B = ctx.plan, ctx.eng, ctx.mode, ctx.B
-        m, n = plan.m, plan.n
-        need_k, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
-        info = ctx.solver.last_info
-        if plan.is_chain:
-            kdev, ksb, kse, u = ctx.saved
-            L = eng.L
-            df = torch.empty((B, n), dtype=torch.float64, device=plan.device)
-            want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
-            dk_e = torch.empty((B, m), dtype=torch.float64, device=plan.device) if want_e else None
-            part = torch.empty((B, plan.n_seg), dtype=torch.float64, device=plan.device)
-            stage = None
-            if 16 * (n - 1) > 160 * 1024 - 2048:
-                stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
-            _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(g_dev), n,
-                                                _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(df), n,
-                                                _hip.ptr(dk_e), m, _hip.ptr(part), n, B, _hip.ptr(stage),
-                                                _stream(plan.device)), "diffhe_chain1d_adjoint")
-            dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
-            dk_elem = dk_e
+    grad_k = None
+    if need_k:
+        if mode == K_SCALAR:
+            grad_k = dk_sample.sum().reshape(ctx.kappa_shape)
+        elif mode == K_SAMPLE:
+            grad_k = dk_sample.reshape(ctx.kappa_shape)
+        elif mode == K_ELEM:
+            grad_k = dk_elem.sum(dim=0).reshape(ctx.kappa_shape)
         else:
-            vals, x, Bp, Bv, scale = ctx.saved
-            rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
-            if ctx.path == "lattice-mgpcg":
-                lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.solver.mg, ctx.vals32)
-            else:
-                lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
-            info.adj_iterations = its
-            info.adj_max_relres = float(relres[:B].max())
-            info.not_converged += bad
-            want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
-            dk_nm = dk_sum = None
-            if need_k and ctx.path == "lattice-mgpcg" and mode in (K_SCALAR, K_SAMPLE):
-                dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
-                if dk_sum is not None and mode == K_SCALAR:
-                    dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
-            if need_k and dk_sum is None:
-                dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e)
-            dk_sample = dk_sum[:B] if need_k else None
-            dk_elem = None
-            if need_k and want_e:
-                dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
-            df = eng.to_sample_major(eng.apply_M(lam, Bp), B, Bp, n) if need_f else None
+            grad_k = dk_elem.reshape(ctx.kappa_shape)
+        grad_k = grad_k.to(ctx.kappa_device)
+    grad_f = None
+    if need_f:
+        grad_f = df if ctx.batched_f else df.sum(dim=0)
+        grad_f = grad_f.to(ctx.out_device)
+    return grad_k, grad_f
 
-        grad_k = None
-        if need_k:
-            if mode == K_SCALAR:
-                grad_k = dk_sample.sum().reshape(ctx.kappa_shape)
-            elif mode == K_SAMPLE:
-                grad_k = dk_sample.reshape(ctx.kappa_shape)
-            elif mode == K_ELEM:
-                grad_k = dk_elem.sum(dim=0).reshape(ctx.kappa_shape)
-            else:
-                grad_k = dk_elem.reshape(ctx.kappa_shape)
-            grad_k = grad_k.to(ctx.kappa_device)
-        grad_f = None
-        if need_f:
-            grad_f = df if ctx.batched_f else df.sum(dim=0)
-            grad_f = grad_f.to(ctx.out_device)
-        return grad_k, grad_f, None
+
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.library custom ops: diffhe::fe_solve (forward) and diffhe::fe_solve_backward (adjoint).
+# Non-tensor context (the solver, the per-call adjoint state) travels as integer handles.
+# ---------------------------------------------------------------------------------------------
+_SOLVERS: "weakref.WeakValueDictionary[int, DifferentiableFESolver]" = weakref.WeakValueDictionary()
+_STATES: Dict[int, object] = {}
+_TOKENS = itertools.count(1)
+_MAX_PENDING_STATES = 4     # forward calls whose backward never ran (e.g. dropped graphs)
+
+
+@torch.library.custom_op("diffhe::fe_solve", mutates_args=())
+def fe_solve(kappa: torch.Tensor, f: torch.Tensor, handle: int, save: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(u, token) = solve with the solver registered under `handle`; `token` names the saved
+    adjoint state (0 when `save` is false)."""
+    solver = _SOLVERS[handle]
+    u, state = _solve_forward(solver, kappa, f)
+    token = 0
+    if save:
+        token = next(_TOKENS)
+        _STATES[token] = state
+        while len(_STATES) > _MAX_PENDING_STATES:
+            _STATES.pop(next(iter(_STATES)))
+    return u, torch.tensor(token, dtype=torch.int64)
+
+
+@fe_solve.register_fake
+def _fe_solve_fake(kappa, f, handle, save):
+    solver = _SOLVERS[handle]
+    n, m = solver.mesh.n_nodes, solver.mesh.n_elements
+    B_f = f.shape[0] if f.dim() == 2 else None
+    _, B_k = _kappa_mode(kappa, m, B_f)
+    B = B_f if B_f is not None else (B_k if B_k is not None else 1)
+    shape = (B, n) if (f.dim() == 2 or B > 1) else (n,)
+    return f.new_empty(shape, dtype=torch.float64), torch.empty((), dtype=torch.int64)
+
+
+@torch.library.custom_op("diffhe::fe_solve_backward", mutates_args=())
+def fe_solve_backward(gbar: torch.Tensor, token: torch.Tensor, need_k: bool, need_f: bool,
+                      kappa_like: torch.Tensor, f_like: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dL/dkappa, dL/df) for the forward call named by `token`; unused gradients come back empty."""
+    state = _STATES.pop(int(token), None)
+    if state is None:
+        raise RuntimeError("diffhe: adjoint state of this solve is gone (backward ran twice, or more than "
+                           f"{_MAX_PENDING_STATES} un-differentiated solves are pending)")
+    gk, gf = _solve_backward(state, gbar, need_k, need_f)
+    return (gk if gk is not None else kappa_like.new_empty(0), gf if gf is not None else f_like.new_empty(0))
+
+
+@fe_solve_backward.register_fake
+def _fe_solve_backward_fake(gbar, token, need_k, need_f, kappa_like, f_like):
+    return (torch.empty_like(kappa_like) if need_k else kappa_like.new_empty(0),
+            torch.empty_like(f_like) if need_f else f_like.new_empty(0))
+
+
+def _fe_setup_context(ctx, inputs, output):
+    kappa, f, _, _ = inputs
+    ctx.save_for_backward(output[1], kappa, f)
+
+
+def _fe_backward(ctx, grad_u, _grad_token):
+    token, kappa, f = ctx.saved_tensors
+    need_k, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    gk, gf = torch.ops.diffhe.fe_solve_backward(grad_u, token, need_k, need_f, kappa, f)
+    return (gk if need_k else None), (gf if need_f else None), None, None
+
+
+torch.library.register_autograd("diffhe::fe_solve", _fe_backward, setup_context=_fe_setup_context)
 
 
 class DifferentiableFESolver(nn.Module):
@@ -459,7 +533,10 @@ class DifferentiableFESolver(nn.Module):
             raise ValueError(f"f must be (n,) or (B,n) with n={n}, got {tuple(f.shape)}")
         elif f64.dim() == 1 and f64.shape[0] != n:
             raise ValueError(f"f must have {n} nodal values, got {f64.shape[0]}")
-        return _FESolve.apply(self._kappa, f64, self)
+        _SOLVERS[id(self)] = self
+        save = torch.is_grad_enabled() and (self._kappa.requires_grad or f64.requires_grad)
+        u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, id(self), save)
+        return u
 
     # reference-private names kept as aliases; both run the HIP path
     def _solve_1d(self, f: torch.Tensor) -> torch.Tensor:

@@ -559,3 +559,22 @@ def test_empty_and_degenerate_inputs():
     u2 = DifferentiableFESolver(mesh2, 1.3)(f)
     uo = orc.solve(nodes, el, bn, bv, 1.3, f.numpy())
     assert rel_err(u2.numpy(), uo) < RTOL_U
+
+
+def test_custom_op_state_lifecycle():
+    """Adjoint state is held only between forward and backward of a differentiated call."""
+    from diffhe import solver as S
+    mesh = FEMesh.rectangle(8, 8)
+    k = torch.tensor(1.3, dtype=T64, requires_grad=True)
+    f = torch.ones(mesh.n_nodes, dtype=T64)
+    S._STATES.clear()
+    with torch.no_grad():
+        DifferentiableFESolver(mesh, k)(f)
+    assert len(S._STATES) == 0                                  # nothing saved without grad
+    u = DifferentiableFESolver(mesh, k)(f)
+    assert len(S._STATES) == 1
+    u.sum().backward()
+    assert len(S._STATES) == 0 and k.grad is not None           # consumed by the adjoint
+    for _ in range(3 * S._MAX_PENDING_STATES):                  # graphs that are dropped do not leak
+        DifferentiableFESolver(mesh, k)(f)
+    assert len(S._STATES) <= S._MAX_PENDING_STATES

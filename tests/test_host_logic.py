@@ -222,3 +222,25 @@ def test_bc_arrays():
     mesh = FEMesh.line(4, bc_left=1.5, bc_right=None)
     is_bc, g = _bc_arrays(mesh)
     assert is_bc.tolist() == [1, 0, 0, 0, 0] and g.tolist() == [1.5, 0, 0, 0, 0]
+
+
+def test_custom_ops_are_registered_with_shape_inference():
+    """The solve is exposed as torch.library ops (diffhe::fe_solve / diffhe::fe_solve_backward) with
+    fake (meta) implementations, so tracing needs no GPU."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from diffhe import solver as S
+    assert hasattr(torch.ops.diffhe, "fe_solve") and hasattr(torch.ops.diffhe, "fe_solve_backward")
+    mesh = FEMesh.rectangle(4, 4)
+    s = DifferentiableFESolver(mesh)
+    S._SOLVERS[id(s)] = s
+    with FakeTensorMode():
+        k1, f1 = torch.empty((), dtype=torch.float64), torch.empty(25, dtype=torch.float64)
+        u, tok = torch.ops.diffhe.fe_solve(k1, f1, id(s), False)
+        assert u.shape == (25,) and u.dtype == torch.float64 and tok.shape == ()
+        kb, fb = torch.empty(6, dtype=torch.float64), torch.empty(6, 25, dtype=torch.float64)
+        u, _ = torch.ops.diffhe.fe_solve(kb, fb, id(s), False)
+        assert u.shape == (6, 25)
+        u, _ = torch.ops.diffhe.fe_solve(kb, f1, id(s), False)          # kappa batch, shared f
+        assert u.shape == (6, 25)
+        gk, gf = torch.ops.diffhe.fe_solve_backward(u, tok, True, False, kb, f1)
+        assert gk.shape == (6,) and gf.numel() == 0
