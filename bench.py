@@ -140,6 +140,7 @@ def main():
         Bp = padded_batch(B)
         roof = None
         traffic = None
+        copy_gbs = None
         roofline_ok = (solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample") or \
             solver.last_info.path == "ell-pcg"
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -180,6 +181,9 @@ def main():
                     traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
+            # stream-copy reference on the same vectors (read one, write one), measured the same way
+            copy_dur = time_launch(lambda: y.copy_(x))
+            copy_gbs = 16.0 * n * Bp / copy_dur / 1e9
             del x, rhs, y, vals
         elif solver.last_info.path == "ell-pcg":
             W = plan.W
@@ -197,7 +201,8 @@ def main():
             achieved = alg_bytes / dur / 1e9
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4)}
+                    "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4),
+                    "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None}
 
         # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------
         cpu = None

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Demo of the HIP solve path (needs an MI355X): 1D exactness, kappa recovery through the adjoint
+(the scenario of the reference's examples/poisson_1d_demo.py:88-112), and a batched 2D solve."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "difffe-physics-lab_amd"))
+import torch  # noqa: E402
+from diffhe import FEMesh, DifferentiableFESolver  # noqa: E402
+
+T64 = torch.float64
+
+# --- 1D: -u'' = 1, u(0) = u(1) = 0, exact nodal values x(1-x)/2 --------------------------------
+mesh = FEMesh.line(n_elements=20)
+x = mesh.nodes.squeeze(1)
+u = DifferentiableFESolver(mesh)(torch.ones_like(x))
+print(f"[1D] max nodal error vs x(1-x)/2: {float((u - x * (1 - x) / 2).abs().max()):.2e}")
+
+# --- recover kappa = 2 from data by Adam through the differentiable solve -------------------------
+mesh = FEMesh.line(n_elements=30)
+f = torch.ones(mesh.n_nodes, dtype=T64)
+with torch.no_grad():
+    u_data = DifferentiableFESolver(mesh, 2.0)(f)
+kappa = torch.tensor(1.0, dtype=T64, requires_grad=True)
+opt = torch.optim.Adam([kappa], lr=0.1)
+for _ in range(200):
+    opt.zero_grad()
+    loss = ((DifferentiableFESolver(mesh, kappa.abs())(f) - u_data) ** 2).mean()
+    loss.backward()
+    opt.step()
+print(f"[1D] recovered kappa = {float(kappa.detach().abs()):.4f} (true 2.0000), loss {float(loss):.2e}")
+
+# --- 2D: 256 kappa samples on a 512 x 512 mesh, forward + adjoint -----------------------------------
+mesh = FEMesh.rectangle(512, 512)
+dev = torch.device("cuda")
+kappa = (0.5 + 1.5 * torch.rand(256, dtype=T64, device=dev)).requires_grad_(True)
+f = torch.ones(256, mesh.n_nodes, dtype=T64, device=dev)
+solver = DifferentiableFESolver(mesh, kappa)
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kappa.grad = None
+    u = solver(f)
+    (u ** 2).sum(dim=1).mean().backward()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"[2D] 256 differentiable solves on 512^2 in {dt * 1e3:.1f} ms ({256 / dt:.0f} solves/s), "
+      f"{solver.last_info.iterations}+{solver.last_info.adj_iterations} PCG iterations, "
+      f"relres {solver.last_info.max_relres:.1e}; dL/dkappa identity err "
+      f"{float((kappa.grad + 2 * (u.detach() ** 2).sum(1) / 256 / kappa.detach()).abs().max()):.1e}")
