@@ -406,6 +406,35 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 #undef STRIP
 }
 
+// One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
+//   d_out = c1 d_in + c2 D^-1 (b - A x_in) ;  x_out = x_in + d_out        (d_in == NULL: c1 = 0)
+// part (optional): per-sample partial of b.x_out, as in dia_jacobi_kernel.
+template <typename TV>
+__global__ __launch_bounds__(256) void dia_cheby_kernel(Level L, int Bv, const double* __restrict__ scale,
+                                                         const TV* __restrict__ bvec, const TV* __restrict__ xin,
+                                                         const TV* __restrict__ din, TV* __restrict__ xout,
+                                                         TV* __restrict__ dout, double c1, double c2,
+                                                         double* __restrict__ part, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  for (int i = nm.node0; i < L.n; i += nm.stride) {
+    const i64 o = (i64)i * Bp + nm.b;
+    const double sc = row_scale(L, scale, i, nm.b);
+    const double d = sc * L.v[(i64)i * Bv + vb];
+    const double bi = (double)bvec[o];
+    const double xi = xin ? (double)xin[o] : 0.0;
+    const double res = xin ? bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp) : bi;
+    const double dn = (din ? c1 * (double)din[o] : 0.0) + c2 * res / d;
+    dout[o] = (TV)dn;
+    const double xo = xi + dn;
+    xout[o] = (TV)xo;
+    s += bi * xo;
+  }
+  if (part) STORE_PARTIAL(part, s);
+}
+
 // coarse rhs = P^T r (P = P1 interpolation on the nested triangulation), 0 on coarse Dirichlet rows
 template <typename TV>
 __global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, const TV* __restrict__ r,
@@ -769,6 +798,38 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
   return lgrid(L.n, H.Bp).x;
 }
 
+// Coarsest-level solve: Chebyshev semi-iteration for D^-1 A with the spectrum bounds of the P1 Laplacian
+// on an nx x ny lattice, lambda in [ (1 - cos(pi/nx))/2 + (1 - cos(pi/ny))/2 , 2 ]; the lower bound is halved
+// for safety (below it the polynomial stays < 1, it only damps less).  The degree follows from the size, so a
+// 3 x 3 coarsest grid costs ~5 steps and a 125 x 125 one (sizes that cannot be halved further) ~170 --
+// a fixed polynomial in A, hence still a symmetric preconditioner.  Returns the solution buffer.
+template <typename TV>
+TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks, hipStream_t st) {
+  const Level& L = H.lev[l];
+  const double pi = 3.14159265358979323846;
+  const double lmin = 0.5 * (0.5 * (1.0 - cos(pi / L.nx)) + 0.5 * (1.0 - cos(pi / L.ny)));
+  const double lmax = 2.0;
+  int deg = (int)ceil(1.5 * sqrt(lmax / lmin));
+  if (deg < H.n_coarse) deg = H.n_coarse;
+  if (deg > 400) deg = 400;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  TV* xa = (TV*)H.xa[l];
+  TV* xb = (TV*)H.xb[l];
+  TV* d = (TV*)H.res[l];  // the coarsest level never restricts: its residual buffer holds d
+  double rho = 1.0 / sigma;
+  LAUNCH(dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, (const TV*)nullptr, xa, d, 0.0,
+         1.0 / theta, (deg == 1) ? part : (double*)nullptr, H.Bp);
+  for (int k = 1; k < deg; ++k) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    LAUNCH(dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, (const TV*)d, xb, d, rho_new * rho,
+           2.0 * rho_new / delta, (k == deg - 1) ? part : (double*)nullptr, H.Bp);
+    rho = rho_new;
+    TV* t = xa; xa = xb; xb = t;
+  }
+  if (nblocks) *nblocks = lgrid(L.n, H.Bp).x;
+  return xa;
+}
+
 // z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
 // fine sweep also leaves the partials of rhs0.z there (*rz_blocks of them).
 template <typename TV>
@@ -779,8 +840,14 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
   const int last = H.nl - 1;
   for (int l = l0; l <= last; ++l) {  // downward leg
     const Level& L = H.lev[l];
-    const int sweeps = (l == last) ? H.n_coarse : H.nu;
-    const bool only = (l0 == last);  // no coarser level: the cycle is `sweeps` Jacobi sweeps
+    if (l == last) {  // coarsest level: Chebyshev solve (also the whole cycle when there is one level)
+      int nb = 0;
+      cur[l] = coarse_solve<TV>(H, l, rhs[l], (l0 == last) ? rz_part : nullptr, &nb, st);
+      if (l0 == last && rz_part && rz_blocks) *rz_blocks = nb;
+      break;
+    }
+    const int sweeps = H.nu;
+    const bool only = false;
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
     int done;

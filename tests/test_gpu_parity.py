@@ -578,3 +578,24 @@ def test_custom_op_state_lifecycle():
     for _ in range(3 * S._MAX_PENDING_STATES):                  # graphs that are dropped do not leak
         DifferentiableFESolver(mesh, k)(f)
     assert len(S._STATES) <= S._MAX_PENDING_STATES
+
+
+@pytest.mark.parametrize("nx,ny", [(100, 37), (250, 250), (96, 72)])
+def test_lattice_sizes_that_do_not_halve(nx, ny):
+    """Lattices whose sizes stop halving early keep a large coarsest level: its Chebyshev solve
+    (degree from the level size) keeps the PCG iteration count mesh-independent."""
+    mesh = FEMesh.rectangle(nx, ny, (0.0, 1.0), (0.0, 0.5), 0.1)
+    nodes, el, bn, bv = arrays(mesh)
+    rng = np.random.default_rng(31)
+    B = 4
+    kap = rng.uniform(0.5, 2.0, B)
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    kt = torch.from_numpy(kap).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(torch.from_numpy(f))
+    (u ** 2).sum().backward()
+    assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.iterations <= 16
+    for b in (0, B - 1):
+        uo, dko, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
+        assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+        assert abs(float(kt.grad[b]) - dko.sum()) <= RTOL_GRAD * abs(dko.sum())
