@@ -230,8 +230,10 @@ class _Engine:
         # per-sweep Jacobi damping: Chebyshev weights for the interval [0.5, 2] of D^-1 A when nu == 2
         omegas = mg.get("omegas") or ([0.56, 1.39] if mg["nu"] == 2 else [mg["omega"]] * mg["nu"])
         om = (ctypes.c_double * len(omegas))(*omegas)
+        # a multigrid-preconditioned CG that has not converged in a few hundred iterations never will:
+        # bound the loop so a defect surfaces as `not_converged` instead of minutes of GPU time
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
-                                              self.max_iter, len(omegas), mg["n_coarse"], om,
+                                              min(self.max_iter, 500), len(omegas), mg["n_coarse"], om,
                                               int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
                                               | ((int(mg.get("fmg_cycles", 1)) - 1) << 2), _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
