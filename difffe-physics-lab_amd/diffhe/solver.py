@@ -19,6 +19,7 @@ import ctypes
 import itertools
 import os
 import types
+import warnings
 import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -331,6 +332,9 @@ def _solve_forward(solver, kappa, f):
         ctx.saved = (vals, x, Bp, Bv, None)
     solver.last_info = info
     ctx.path = info.path
+    if info.not_converged:
+        warnings.warn(f"diffhe: {info.not_converged} of {B} systems did not reach tol={solver.tol:g} "
+                      f"(max relative residual {info.max_relres:.2e}, path {info.path})", RuntimeWarning)
     out = u if batched or B > 1 else u[0]
     return out.to(out_device), ctx
 
