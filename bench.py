@@ -156,35 +156,52 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
 
+        other = None
         if solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample":
-            # dominant kernel: one damped-Jacobi sweep of the V-cycle on the fine level (dia_strip_kernel,
-            # M_JACOBI), run on the operator this workload assembles (shared unit matrix + kappa_b scale)
+            # The kernel with the largest share of the step (profiles/r01_mgpcg_final_kernel_stats.csv) is the
+            # fused CG step dia_strip_kernel<M_APPLY, F_PUPD> (p = z + beta p, x += alpha p_old, Ap = A p, p.Ap);
+            # it is timed alone on the operator this workload assembles (shared unit matrix + kappa_b scale).
             from diffhe.solver import _Engine, K_SAMPLE
             eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
             vals, Bv, scale, _, _ = eng.lattice_assemble(kappa.detach(), K_SAMPLE, B, Bp)
             arr = eng.lattice_levels(vals)
+            f32 = bool(solver.mg.get("fp32"))
+            z = torch.rand((n, Bp), dtype=torch.float32 if f32 else torch.float64, device=dev)
             x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+            p_in = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+            p_out = torch.empty_like(p_in)
+            Ap = torch.empty_like(p_in)
+            ab = torch.rand(2, Bp, dtype=torch.float64, device=dev)
+            part = torch.empty(L.diffhe_lattice_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
+            dur = time_launch(lambda: _hip.check(L.diffhe_lattice_cg_step(
+                arr, Bv, _hip.ptr(scale), _hip.ptr(z), int(f32), _hip.ptr(p_in), _hip.ptr(p_out), _hip.ptr(x),
+                _hip.ptr(ab[0]), _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), Bp, st), "diffhe_lattice_cg_step"))
+            zb = 4.0 if f32 else 8.0
+            alg_bytes = (zb + 40.0) * n * Bp     # read z, p, x; write p, Ap, x (matrix batch-shared: amortised)
+            kname = "dia_strip_kernel<M_APPLY,F_PUPD> (fused CG step: p-update + x-update + operator apply + dot)"
+            pmc_key = "F_PUPD"
+            # second kernel family: one weighted-Jacobi sweep of the V-cycle on the fine level, fp64 storage
             rhs = torch.rand((n, Bp), dtype=torch.float64, device=dev)
-            y = torch.empty_like(x)
-            dur = time_launch(lambda: _hip.check(L.diffhe_lattice_smooth(
-                arr, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), _hip.ptr(y), solver.mg["omega"], Bp, st),
+            dur_j = time_launch(lambda: _hip.check(L.diffhe_lattice_smooth(
+                arr, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), _hip.ptr(p_out), 0.8, Bp, st),
                 "diffhe_lattice_smooth"))
-            alg_bytes = 24.0 * n * Bp           # read x, rhs; write x (matrix is batch-shared: amortised)
-            kname = "dia_strip_kernel<M_JACOBI> (fine-level Jacobi sweep)"
-            # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same sizes;
-            # FETCH_SIZE doubled per the guide's gfx950 correction) -- only valid for the contract workload
-            try:
+            copy_dur = time_launch(lambda: p_out.copy_(x))
+            copy_gbs = 16.0 * n * Bp / copy_dur / 1e9
+            other = [{"kernel": "dia_strip_kernel<M_JACOBI> (fine-level Jacobi sweep, fp64 storage)",
+                      "achieved": round(24.0 * n * Bp / dur_j / 1e9, 1), "frac": round(24.0 * n * Bp / dur_j / 8e12, 4),
+                      "bytes_per_launch": 24.0 * n * Bp, "avg_launch_ms": round(dur_j * 1e3, 4)}]
+            try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernels, same sizes)
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
                     pmc = json.load(fh)
                 if pmc["pass_bytes"] == 8 * n * Bp:
-                    key = [k for k in pmc["kernels"] if "dia_strip_kernel<double, double, 2, 0" in k][0]
-                    traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                    for k_, v_ in pmc["kernels"].items():
+                        if "dia_strip_kernel<double, float, double, 0, 2" in k_ and f32:
+                            traffic = v_["hbm_bytes_per_launch"]
+                        if "dia_strip_kernel<double, double, double, 2, 0" in k_:
+                            other[0]["traffic"] = v_["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-            # stream-copy reference on the same vectors (read one, write one), measured the same way
-            copy_dur = time_launch(lambda: y.copy_(x))
-            copy_gbs = 16.0 * n * Bp / copy_dur / 1e9
-            del x, rhs, y, vals
+            del z, x, p_in, p_out, Ap, rhs, vals
         elif solver.last_info.path == "ell-pcg":
             W = plan.W
             vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
@@ -202,7 +219,7 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4),
-                    "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None}
+                    "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None, "other_kernels": other}
 
         # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------
         cpu = None

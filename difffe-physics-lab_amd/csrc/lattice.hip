@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
 }
 
 constexpr int kStripCols = 8;
+constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused CG kernel: fewer VGPRs, more waves
 constexpr int kPartBlocks = 2048;  // capacity (in blocks) of every partial-sum buffer
 
 struct StripGeom {
@@ -1048,7 +1049,6 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
   // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
-  constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused kernel: fewer VGPRs, more waves
   const StripGeom g0 = strip_geom(L0, Bp, kPupdCols);
   const bool fused = g0.use;
   const void* z = nullptr;
@@ -1149,6 +1149,30 @@ extern "C" int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, con
   PcgScalars S{};
   hipLaunchKernelGGL(pcg_scalar_kernel, dim3((Bp + 63) / 64), dim3(1024), 0, st, (int)S_SUM, (const double*)part,
                      g.ncb * g.nrc, Bp, 0.0, S, out);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z,
+                                      int z_fp32, const double* p_in, double* p_out, double* x, const double* alpha,
+                                      const double* beta, int first, double* Ap, double* part, int Bp, void* stream) {
+  if (!z || !p_out || !x || !Ap || !part || (!first && (!p_in || !alpha || !beta))) return DIFFHE_E_BADARG;
+  Hier H;
+  const double w1 = 0.8;
+  int rc = fill_hier(H, level, 1, Bv, Bp, scale, &w1, 1, 1);
+  if (rc) return rc;
+  const StripGeom g = strip_geom(H.lev[0], Bp, kPupdCols);
+  if (!g.use) return DIFFHE_E_TOOBIG;
+  Extra ex{};
+  ex.a0 = z; ex.p_in = p_in; ex.p_out = p_out; ex.x = x; ex.alpha = alpha; ex.beta = beta; ex.first = first;
+  hipStream_t st = (hipStream_t)stream;
+  if (z_fp32)
+    launch_strip<double, M_APPLY, false, F_PUPD, float, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,
+                                                                   (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st,
+                                                                   ex);
+  else
+    launch_strip<double, M_APPLY, false, F_PUPD, double, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,
+                                                                    (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st,
+                                                                    ex);
   return diffhe::check_launch();
 }
 

@@ -192,6 +192,14 @@ int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* sca
                          double* part, int Bp, void* stream);
 int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,
                           const double* xin, double* xout, double omega, int Bp, void* stream);
+/* The fused CG step of diffhe_lattice_pcg_solve as a single launch (timing / tests):
+ *   p_out = z + beta[b] p_in (first != 0: p_out = z);  x += alpha[b] p_in (skipped when first);
+ *   Ap = A p_out;  part = block partials of p_out . Ap.   z is (n, Bp) fp32 (z_fp32 != 0) or fp64.
+ * p_in and p_out must be different buffers (halo reads of p_in).  DIFFHE_E_TOOBIG below the
+ * strip-kernel threshold. */
+int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z, int z_fp32,
+                           const double* p_in, double* p_out, double* x, const double* alpha, const double* beta,
+                           int first, double* Ap, double* part, int Bp, void* stream);
 /* out[b] = sum_i lam[i,b] * ((A x)[i,b] + add[i]): the dL/dkappa contraction of a batch-FACTORED
  * operator (K_b = kappa_b K_1: -lam^T K_1 u with u = x + g, add = K_1[free,bc] g), one pass over
  * x and lam instead of the element loop.  Returns DIFFHE_E_TOOBIG when the mesh/batch is below the

@@ -599,3 +599,50 @@ def test_lattice_sizes_that_do_not_halve(nx, ny):
         uo, dko, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
         assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
         assert abs(float(kt.grad[b]) - dko.sum()) <= RTOL_GRAD * abs(dko.sum())
+
+
+def test_fused_cg_step_kernel_vs_reference_formulas():
+    """diffhe_lattice_cg_step: p' = z + beta p, x += alpha p, Ap = A p', partial dots -- against torch on
+    the same operator (dense K from the oracle), fp32 and fp64 z, first and later iterations."""
+    from diffhe.solver import _Engine, K_SAMPLE
+    nx, ny = 200, 70
+    mesh = FEMesh.rectangle(nx, ny, (0.0, 2.0), (0.0, 0.7), 0.0)
+    nodes, el, bn, bv = arrays(mesh)
+    n = mesh.n_nodes
+    dev = torch.device("cuda", 0)
+    plan = get_plan(mesh, dev)
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B = 64
+    rng = np.random.default_rng(3)
+    kap = rng.uniform(0.5, 2.0, B)
+    eng = _Engine(plan, 1e-12, 100, 1, "gather")
+    vals, Bv, scale, _, _ = eng.lattice_assemble(torch.from_numpy(kap), K_SAMPLE, B, B)
+    arr = eng.lattice_levels(vals)
+    free = np.ones(n, bool)
+    free[bn] = False
+    mk = lambda: torch.from_numpy(rng.standard_normal((n, B)) * free[:, None]).to(dev)   # noqa: E731
+    z64, p_in, x0 = mk(), mk(), mk()
+    alpha = torch.from_numpy(rng.uniform(0.1, 1.0, B)).to(dev)
+    beta = torch.from_numpy(rng.uniform(0.1, 1.0, B)).to(dev)
+    import scipy.sparse as sp
+    K1, _ = orc.assemble_sparse(nodes, el, 1.0, np.zeros(n))
+    K1 = sp.diags(free.astype(float)) @ K1 @ sp.diags(free.astype(float)) + sp.diags((~free).astype(float))
+    part = torch.empty(L.diffhe_lattice_blocks(n, B) * B, dtype=T64, device=dev)
+    for z_fp32 in (0, 1):
+        z = z64.float() if z_fp32 else z64
+        zr = z.double().cpu().numpy()
+        for first in (1, 0):
+            x = x0.clone()
+            p_out = torch.empty_like(p_in)
+            Ap = torch.empty_like(p_in)
+            rc = L.diffhe_lattice_cg_step(arr, Bv, _hip.ptr(scale), _hip.ptr(z), z_fp32, _hip.ptr(p_in), _hip.ptr(p_out),
+                                          _hip.ptr(x), _hip.ptr(alpha), _hip.ptr(beta), first, _hip.ptr(Ap),
+                                          _hip.ptr(part), B, st)
+            assert rc == 0
+            p_ref = zr if first else zr + beta.cpu().numpy() * p_in.cpu().numpy()
+            x_ref = x0.cpu().numpy() if first else x0.cpu().numpy() + alpha.cpu().numpy() * p_in.cpu().numpy()
+            Ap_ref = (K1 @ p_ref) * np.where(free[:, None], kap[None, :], 1.0)
+            assert rel_err(p_out.cpu().numpy(), p_ref) < 1e-14
+            assert rel_err(x.cpu().numpy(), x_ref) < 1e-14
+            assert rel_err(Ap.cpu().numpy(), Ap_ref) < 1e-13
