@@ -144,8 +144,8 @@ enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2 };
 
 struct Extra {
   const void* a0;           // F_PROLONG: coarse correction e (TA);  F_PUPD: z (TA)
-  const double* p_in;       // F_PUPD
-  double* p_out;            // F_PUPD
+  const void* p_in;         // F_PUPD: previous search direction, stored as TA (the type of z)
+  void* p_out;              // F_PUPD: new search direction, stored as TA
   double* x;                // F_PUPD: iterate, updated in place
   const double* alpha;      // F_PUPD: per-sample alpha of the previous iteration
   const double* beta;       // F_PUPD
@@ -202,8 +202,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const TA* __restrict__ aux = (const TA*)ex.a0;
   // F_PUPD row pointers at (row, c0w), advanced with the others
   const TA* __restrict__ pz = (FUSE == F_PUPD) ? aux + i0 * Bp : nullptr;
-  const double* __restrict__ ppi = (FUSE == F_PUPD) ? ex.p_in + i0 * Bp : nullptr;
-  double* __restrict__ ppo = (FUSE == F_PUPD) ? ex.p_out + i0 * Bp : nullptr;
+  const TA* __restrict__ ppi = (FUSE == F_PUPD) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
+  TA* __restrict__ ppo = (FUSE == F_PUPD) ? (TA*)ex.p_out + i0 * Bp : nullptr;
   double* __restrict__ pxx = (FUSE == F_PUPD) ? ex.x + i0 * Bp : nullptr;
 
   // `row` is the grid row being loaded; xrow / d0row point at (row, c0w); roff = offset of that
@@ -227,7 +227,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       if (FUSE == F_PUPD) {
         const i64 o = roff + (i64)dq[q] * Bp;
         v = (double)(pz + o)[lb];
-        if (!ex.first) v += beta * (ppi + o)[lb];
+        if (!ex.first) v += beta * (double)(ppi + o)[lb];
+        // the direction is STORED as TA: use the stored (rounded) value everywhere, so that Ap = A p,
+        // x += alpha p and r -= alpha Ap stay exactly consistent (r == b - A x is independent of p)
+        v = (double)(TA)v;
       } else {
         v = (double)(xrow + (i64)dq[q] * Bp)[lb];
       }
@@ -296,8 +299,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           s += y * xc[q];
         }
         if (FUSE == F_PUPD) {  // store the new direction; apply the pending x += alpha_prev * p_old
-          (ppo + o)[lb] = xc[q];
-          if (!ex.first) (pxx + o)[lb] += alpha_prev * (ppi + o)[lb];
+          (ppo + o)[lb] = (TA)xc[q];
+          if (!ex.first) (pxx + o)[lb] += alpha_prev * (double)(ppi + o)[lb];
         }
       } else {
         const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega_in : (double)(pb + o)[lb];
@@ -628,13 +631,14 @@ __global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__
 }
 
 // x += alpha p  (flush of the pending iterate update of the fused CG loop)
-__global__ __launch_bounds__(256) void pcg_axpy_kernel(const double* __restrict__ alpha, const double* __restrict__ p,
+template <typename TP>
+__global__ __launch_bounds__(256) void pcg_axpy_kernel(const double* __restrict__ alpha, const TP* __restrict__ p,
                                                         double* __restrict__ x, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   const double a = alpha[nm.b];
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    x[o] += a * p[o];
+    x[o] += a * (double)p[o];
   }
 }
 
@@ -1107,7 +1111,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     n_active = status_host[2];
     if (n_active == 0) break;
   }
-  if (fused && it > 0) LAUNCH(pcg_axpy_kernel, n, (const double*)S.alpha, (const double*)p, x, n, Bp);
+  if (fused && it > 0) {
+    if (f32) LAUNCH(pcg_axpy_kernel<float>, n, (const double*)S.alpha, (const float*)(const void*)p, x, n, Bp);
+    else LAUNCH(pcg_axpy_kernel<double>, n, (const double*)S.alpha, (const double*)p, x, n, Bp);
+  }
   nba = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
   SCALAR(S_RELRES, partA, nba);
   rc = diffhe::check_launch();
@@ -1153,7 +1160,7 @@ extern "C" int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, con
 }
 
 extern "C" int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z,
-                                      int z_fp32, const double* p_in, double* p_out, double* x, const double* alpha,
+                                      int z_fp32, const void* p_in, void* p_out, double* x, const double* alpha,
                                       const double* beta, int first, double* Ap, double* part, int Bp, void* stream) {
   if (!z || !p_out || !x || !Ap || !part || (!first && (!p_in || !alpha || !beta))) return DIFFHE_E_BADARG;
   Hier H;

@@ -173,8 +173,9 @@ typedef struct diffhe_mg_level {
  *   levels   HOST array of n_levels descriptors (device pointers inside)
  *   Bv       Bp (matrix per sample) or 1 (shared); scale (Bp) or NULL: K_b = scale[b]*K on
  *            the free rows (one scalar kappa per sample, solver.py:88,139)
- *   precond_fp32  bit 0: the V-cycle stores its vectors in fp32 (arithmetic stays fp64 in
- *            registers; the outer CG, its residual and all dot products are fp64);
+ *   precond_fp32  bit 0: the V-cycle AND the CG search direction p are stored in fp32 (arithmetic
+ *            stays fp64 in registers; x, r, Ap and all dot products are fp64, and every update
+ *            uses the stored p, so the recursion r = b - A x stays exact);
  *            bit 1: start the CG from a full-multigrid iterate instead of 0
  *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
@@ -194,11 +195,13 @@ int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* sc
                           const double* xin, double* xout, double omega, int Bp, void* stream);
 /* The fused CG step of diffhe_lattice_pcg_solve as a single launch (timing / tests):
  *   p_out = z + beta[b] p_in (first != 0: p_out = z);  x += alpha[b] p_in (skipped when first);
- *   Ap = A p_out;  part = block partials of p_out . Ap.   z is (n, Bp) fp32 (z_fp32 != 0) or fp64.
+ *   Ap = A p_out;  part = block partials of p_out . Ap.   z, p_in and p_out are (n, Bp) fp32
+ *   (z_fp32 != 0) or fp64: the search direction is stored in the precision of the preconditioner
+ *   output; x, Ap and the dots are always fp64 and use the STORED p, so r = b - A x stays exact.
  * p_in and p_out must be different buffers (halo reads of p_in).  DIFFHE_E_TOOBIG below the
  * strip-kernel threshold. */
 int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z, int z_fp32,
-                           const double* p_in, double* p_out, double* x, const double* alpha, const double* beta,
+                           const void* p_in, void* p_out, double* x, const double* alpha, const double* beta,
                            int first, double* Ap, double* part, int Bp, void* stream);
 /* out[b] = sum_i lam[i,b] * ((A x)[i,b] + add[i]): the dL/dkappa contraction of a batch-FACTORED
  * operator (K_b = kappa_b K_1: -lam^T K_1 u with u = x + g, add = K_1[free,bc] g), one pass over

@@ -632,17 +632,21 @@ def test_fused_cg_step_kernel_vs_reference_formulas():
     for z_fp32 in (0, 1):
         z = z64.float() if z_fp32 else z64
         zr = z.double().cpu().numpy()
+        p_st = p_in.float() if z_fp32 else p_in          # the direction is stored in z's precision
         for first in (1, 0):
             x = x0.clone()
-            p_out = torch.empty_like(p_in)
+            p_out = torch.empty_like(p_st)
             Ap = torch.empty_like(p_in)
-            rc = L.diffhe_lattice_cg_step(arr, Bv, _hip.ptr(scale), _hip.ptr(z), z_fp32, _hip.ptr(p_in), _hip.ptr(p_out),
+            rc = L.diffhe_lattice_cg_step(arr, Bv, _hip.ptr(scale), _hip.ptr(z), z_fp32, _hip.ptr(p_st), _hip.ptr(p_out),
                                           _hip.ptr(x), _hip.ptr(alpha), _hip.ptr(beta), first, _hip.ptr(Ap),
                                           _hip.ptr(part), B, st)
             assert rc == 0
-            p_ref = zr if first else zr + beta.cpu().numpy() * p_in.cpu().numpy()
-            x_ref = x0.cpu().numpy() if first else x0.cpu().numpy() + alpha.cpu().numpy() * p_in.cpu().numpy()
+            p_old = p_st.double().cpu().numpy()
+            p_ref = zr if first else zr + beta.cpu().numpy() * p_old
+            if z_fp32:
+                p_ref = p_ref.astype(np.float32).astype(np.float64)     # stored rounded; Ap uses the stored p
+            x_ref = x0.cpu().numpy() if first else x0.cpu().numpy() + alpha.cpu().numpy() * p_old
             Ap_ref = (K1 @ p_ref) * np.where(free[:, None], kap[None, :], 1.0)
-            assert rel_err(p_out.cpu().numpy(), p_ref) < 1e-14
+            assert rel_err(p_out.double().cpu().numpy(), p_ref) < 1e-14
             assert rel_err(x.cpu().numpy(), x_ref) < 1e-14
             assert rel_err(Ap.cpu().numpy(), Ap_ref) < 1e-13

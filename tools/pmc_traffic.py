@@ -31,12 +31,13 @@ torch.cuda.synchronize()
 for _ in range(REPS):   # dominant kernel: dia_strip_kernel<double,...,M_JACOBI>
     _hip.check(L.diffhe_lattice_smooth(arr, Bv, _hip.ptr(scale), _hip.ptr(r), _hip.ptr(x), _hip.ptr(y), 0.8, B, st), "s")
 z32 = torch.rand((n, B), dtype=torch.float32, device=dev)
-p2 = torch.empty_like(x)
+p32_in = torch.rand((n, B), dtype=torch.float32, device=dev)
+p2 = torch.empty_like(p32_in)
 Ap = torch.empty_like(x)
 ab = torch.rand(2, B, dtype=torch.float64, device=dev)
 part = torch.empty(L.diffhe_lattice_blocks(n, B) * B, dtype=torch.float64, device=dev)
 for _ in range(REPS):   # the kernel with the largest time share: fused CG step dia_strip_kernel<M_APPLY,F_PUPD>
-    _hip.check(L.diffhe_lattice_cg_step(arr, Bv, _hip.ptr(scale), _hip.ptr(z32), 1, _hip.ptr(r), _hip.ptr(p2), _hip.ptr(x),
+    _hip.check(L.diffhe_lattice_cg_step(arr, Bv, _hip.ptr(scale), _hip.ptr(z32), 1, _hip.ptr(p32_in), _hip.ptr(p2), _hip.ptr(x),
                                         _hip.ptr(ab[0]), _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), B, st), "cg")
 for _ in range(REPS):   # calibration A: dia_jacobi_kernel (xin = NULL): read 8nB, write 8nB, 8 B/lane
     _hip.check(L.diffhe_lattice_smooth(arr, Bv, _hip.ptr(scale), _hip.ptr(r), None, _hip.ptr(y), 0.8, B, st), "s0")
