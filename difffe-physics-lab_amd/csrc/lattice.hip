@@ -742,7 +742,7 @@ struct Hier {
   void *bF[kMaxLevels], *xF[kMaxLevels];  // full-multigrid start: restricted right-hand sides, iterates
 };
 
-inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 1024); }
+inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 2048); }  // <= kPartBlocks partial rows
 
 #define LAUNCH(kernel, n, ...) hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__)
 
@@ -1180,6 +1180,35 @@ extern "C" int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, cons
     launch_strip<double, M_APPLY, false, F_PUPD, double, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,
                                                                     (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st,
                                                                     ex);
+  return diffhe::check_launch();
+}
+
+// y = is_bc ? 0 : (M x - sub_scale[b] * sub) for a batch-shared symmetric-diagonal matrix M (the load
+// matrix of a lattice mesh): F = M f - lift and df = M^T lambda without the general ELL pattern.
+__global__ __launch_bounds__(256) void dia_shared_apply_kernel(Level L, const double* __restrict__ x,
+                                                                const double* __restrict__ sub, int sub_B,
+                                                                const double* __restrict__ sub_scale,
+                                                                const unsigned char* __restrict__ mask,
+                                                                double* __restrict__ y, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  for (int i = nm.node0; i < L.n; i += nm.stride) {
+    double acc = dia_row(L, 1, 0, x, i, nm.b, Bp);
+    if (sub) acc -= (sub_scale ? sub_scale[nm.b] : 1.0) * sub[(i64)i * sub_B + (sub_B == 1 ? 0 : nm.b)];
+    if (mask && mask[i]) acc = 0.0;
+    y[(i64)i * Bp + nm.b] = acc;
+  }
+}
+
+extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, const double* x,
+                                           const double* sub, int sub_B, const double* sub_scale,
+                                           const unsigned char* mask, double* y, int Bp, void* stream) {
+  if (!vals || !x || !y || nx < 2 || ny < 2 || (nd != 3 && nd != 4)) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
+  Level L;
+  L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
+  hipLaunchKernelGGL(dia_shared_apply_kernel, lgrid(L.n, Bp), dim3(256), 0, (hipStream_t)stream, L, x, sub, sub_B,
+                     sub_scale, mask, y, Bp);
   return diffhe::check_launch();
 }
 

@@ -168,7 +168,7 @@ class LatticeLevel:
     """One level of the multigrid hierarchy of a lattice mesh: geometry, element integrals
     and gather lists on the device.  Level l uses every 2^l-th node of the fine mesh."""
 
-    def __init__(self, nodes2d: np.ndarray, is_bc2d: np.ndarray, device):
+    def __init__(self, nodes2d: np.ndarray, is_bc2d: np.ndarray, device, with_load_matrix: bool = False):
         L = _hip.lib()
         ny, nx = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
         self.nx, self.ny = nx, ny
@@ -184,6 +184,7 @@ class LatticeLevel:
         _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), 2, self.n, self.m,
                                                  _hip.ptr(self.k0), _hip.ptr(m0), _stream(device)),
                    "diffhe_p1_element_integrals")
+        self._m0 = m0 if with_load_matrix else None
         # quad-diagonal coupling b-d: local (1,2) of [a,b,d], local (0,2) of [b,c,d]; exactly 0 for
         # right triangles -> 3 stored diagonals instead of 4
         hyp = max(float(self.k0[5, 0::2].abs().max()), float(self.k0[2, 1::2].abs().max()))
@@ -191,6 +192,16 @@ class LatticeLevel:
         self.store_slot = dev(np.array([0, 1, 2, 3 if self.nd == 4 else -1, -1, -1, -1], dtype=np.int32))
         self._zero_g = None
         self._device = device
+        # load matrix M in symmetric diagonals (all four: the quad diagonal couples through the centroid rule)
+        self.Mvals = None
+        if with_load_matrix:
+            all4 = dev(np.array([0, 1, 2, 3, -1, -1, -1], dtype=np.int32))
+            self.Mvals = torch.empty((4, self.n), dtype=torch.float64, device=device)
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self._m0), None, 0, 0, _hip.ptr(self.ent_ptr),
+                                                  _hip.ptr(self.contrib), _hip.ptr(self.cols), _hip.ptr(all4), None,
+                                                  None, _hip.ptr(self.Mvals), None, self.n, self.m, 7, 1,
+                                                  _stream(device)), "diffhe_ell_assemble_rows(M, lattice)")
+            self._m0 = None
 
     def zero_g(self):
         """Dirichlet values of a coarse level: corrections vanish there."""
@@ -245,14 +256,27 @@ class SolvePlan:
             nodes2d = nodes.reshape(ny + 1, nx + 1, 2)
             bc2d = is_bc.reshape(ny + 1, nx + 1)
             while True:
-                self.levels.append(LatticeLevel(nodes2d, bc2d, device))
+                self.levels.append(LatticeLevel(nodes2d, bc2d, device, with_load_matrix=not self.levels))
                 ny_l, nx_l = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
                 if nx_l % 2 or ny_l % 2 or min(nx_l, ny_l) < 4 or len(self.levels) >= 16:
                     break
                 nodes2d, bc2d = nodes2d[::2, ::2], bc2d[::2, ::2]
 
-        # --- general ELL path (also provides the load matrix M of the lattice path) ---------
-        pat = build_ell_pattern(elements, self.n)
+        # --- general ELL path: built eagerly for general meshes, lazily for lattice meshes (only
+        # method="ell" needs it there; the pattern build costs ~20 s of numpy at 1024^2) ------------
+        self._elements = elements
+        self._ell_ready = False
+        if not self.is_lattice:
+            self.ensure_ell()
+
+    def ensure_ell(self):
+        """ELL pattern, gather lists, element integrals and the ELL load matrix of the general path."""
+        if self._ell_ready:
+            return
+        L = _hip.lib()
+        device = self.device
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        pat = build_ell_pattern(self._elements, self.n)
         self.W = pat["W"]
         self.cols = dev(pat["cols"])
         self.ent_ptr = dev(pat["ent_ptr"])
@@ -271,6 +295,7 @@ class SolvePlan:
                                               _hip.ptr(self.contrib), _hip.ptr(self.cols), None, None, None,
                                               _hip.ptr(self.Mvals), None, self.n, self.m, self.W, 1, stream),
                    "diffhe_ell_assemble_rows(M)")
+        self._ell_ready = True
 
 
 def _stream(device):

@@ -139,18 +139,31 @@ class _Engine:
                                                   st), "diffhe_ell_assemble_rows")
         return vals, lift
 
-    def load_vector(self, f_nm, lift, Bv, Bp, lift_scale=None):
+    def load_vector(self, f_nm, lift, Bv, Bp, lift_scale=None, lattice=False):
         """F = M f - lift_scale * lift on the free rows, 0 on Dirichlet rows."""
         p = self.p
         F = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        if lattice:   # load matrix stored as symmetric diagonals of level 0: no ELL pattern needed
+            lev = p.levels[0]
+            _hip.check(self.L.diffhe_lattice_apply_shared(lev.nx, lev.ny, 4, _hip.ptr(lev.Mvals), _hip.ptr(f_nm),
+                                                          _hip.ptr(lift), Bv, _hip.ptr(lift_scale), _hip.ptr(p.is_bc),
+                                                          _hip.ptr(F), Bp, _stream(p.device)),
+                       "diffhe_lattice_apply_shared")
+            return F
         _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(f_nm), _hip.ptr(lift),
                                                  Bv, _hip.ptr(lift_scale), _hip.ptr(p.is_bc), _hip.ptr(F), p.n, p.W,
                                                  Bp, _stream(p.device)), "diffhe_ell_spmv_shared")
         return F
 
-    def apply_M(self, x_nm, Bp):
+    def apply_M(self, x_nm, Bp, lattice=False):
         p = self.p
         y = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        if lattice:
+            lev = p.levels[0]
+            _hip.check(self.L.diffhe_lattice_apply_shared(lev.nx, lev.ny, 4, _hip.ptr(lev.Mvals), _hip.ptr(x_nm), None,
+                                                          1, None, None, _hip.ptr(y), Bp, _stream(p.device)),
+                       "diffhe_lattice_apply_shared")
+            return y
         _hip.check(self.L.diffhe_ell_spmv_shared(_hip.ptr(p.Mvals), _hip.ptr(p.cols), _hip.ptr(x_nm), None, 1, None,
                                                  None, _hip.ptr(y), p.n, p.W, Bp, _stream(p.device)),
                    "diffhe_ell_spmv_shared")
@@ -262,7 +275,8 @@ class _Engine:
         dk_e = torch.empty((p.m, Bp), dtype=torch.float64, device=p.device) if want_elem else None
         part = torch.empty((nblk, Bp), dtype=torch.float64, device=p.device)
         dk_sum = torch.empty(Bp, dtype=torch.float64, device=p.device)
-        _hip.check(L.diffhe_p1_grad_kappa(_hip.ptr(p.elems), _hip.ptr(p.k0), _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
+        k0 = p.k0 if p._ell_ready else p.levels[0].k0      # lattice meshes keep k0 on level 0
+        _hip.check(L.diffhe_p1_grad_kappa(_hip.ptr(p.elems), _hip.ptr(k0), _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
                                           p.npe, p.m, Bp, _hip.ptr(dk_e), _hip.ptr(part), _hip.ptr(dk_sum),
                                           _stream(p.device)), "diffhe_p1_grad_kappa")
         return dk_e, dk_sum
@@ -308,7 +322,7 @@ def _solve_forward(solver, kappa, f):
         Bp = padded_batch(B)
         vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
-        rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale)
+        rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
         # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
         vals32 = [v.float() for v in vals] if (Bv != 1 and solver.mg.get("fp32")) else None
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, solver.mg, vals32)
@@ -320,6 +334,7 @@ def _solve_forward(solver, kappa, f):
         ctx.lift = lift if Bv == 1 else None
     else:
         info.path = "ell-pcg"
+        plan.ensure_ell()
         Bp = padded_batch(B)
         kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
         vals, lift = eng.assemble(kdev, kse, ksb, Bv)
@@ -384,7 +399,8 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         dk_elem = None
         if need_k and want_e:
             dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
-        df = eng.to_sample_major(eng.apply_M(lam, Bp), B, Bp, n) if need_f else None
+        df = eng.to_sample_major(eng.apply_M(lam, Bp, lattice=(ctx.path == "lattice-mgpcg")), B, Bp, n) \
+            if need_f else None
 
     grad_k = None
     if need_k:

@@ -210,6 +210,12 @@ int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* s
  * part: diffhe_lattice_blocks(n, Bp) * Bp doubles; out (Bp). */
 int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
                             const double* lam, const double* add, double* part, double* out, int Bp, void* stream);
+/* y = mask ? 0 : (M x - sub_scale[b] * sub) for a batch-shared symmetric-diagonal matrix M (nd, n) of a
+ * lattice mesh: the load vector F = M f minus the Dirichlet lift (solver.py:143-145, :166-169) and the
+ * adjoint df = M^T lambda, without the general ELL pattern.  Arguments as diffhe_ell_spmv_shared. */
+int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, const double* x, const double* sub,
+                                int sub_B, const double* sub_scale, const unsigned char* mask, double* y, int Bp,
+                                void* stream);
 /* kappa_coarse[E] = mean of the 4 children of coarse triangle E; arrays (m, Bv). */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
                                   int Bv, void* stream);

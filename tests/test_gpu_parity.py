@@ -88,6 +88,7 @@ def test_assembled_system_golden(name):
                    dirichlet_nodes={})
     dev = torch.device("cuda")
     plan = get_plan(mesh2, dev)
+    plan.ensure_ell()            # lattice meshes build the general ELL pattern lazily
     assert not plan.is_chain
     L = _hip.lib()
     st = torch.cuda.current_stream().cuda_stream
