@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
 // the 2 halo columns per strip, (RW+2)/RW loads per output) instead of once per stencil leg;
 // the 4 waves of a block own 4 adjacent strips, so halo columns hit L1/L2.  Along a row the
 // coefficients of a strip are CONTIGUOUS, so with a batch-shared matrix (Bv == 1) they arrive
-// as a handful of wide scalar loads per row (s_load_dwordx16) -- no per-lane traffic at all.
+// as scalar loads off one SGPR base per diagonal -- no per-lane traffic at all.
 //
 // Invariant relied upon (and kept by every kernel of the solver): all vectors vanish on
 // Dirichlet rows, whose matrix rows are identity rows.  It lets the per-sample scale s_b be
