@@ -439,24 +439,37 @@ __global__ __launch_bounds__(256) void dia_cheby_kernel(Level L, int Bv, const d
   if (part) STORE_PARTIAL(part, s);
 }
 
-// coarse rhs = P^T r (P = P1 interpolation on the nested triangulation), 0 on coarse Dirichlet rows
+// Coarsening of a level pair: both directions (2:1 nested triangulations, P = P1 interpolation with the
+// quad-diagonal midpoints) or ONE direction only (semi-coarsening, used while the mesh is anisotropic:
+// P = 1D linear interpolation along the coarsened direction).
+__device__ inline int coarsen_x(const Level& F, const Level& C) { return F.nx == 2 * C.nx ? 2 : 1; }
+__device__ inline int coarsen_y(const Level& F, const Level& C) { return F.ny == 2 * C.ny ? 2 : 1; }
+
+// coarse rhs = P^T r, 0 on coarse Dirichlet rows
 template <typename TV>
 __global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, const TV* __restrict__ r,
                                                            TV* __restrict__ rc, int Bp) {
   const NodeMap nm = node_map(Bp);
+  const int sx = coarsen_x(F, C), sy = coarsen_y(F, C);
   for (int I = nm.node0; I < C.n; I += nm.stride) {
     double out = 0.0;
     if (!C.bc[I]) {
       const int ci = I / C.W, cj = I - ci * C.W;
-      const int fi = 2 * ci, fj = 2 * cj;
+      const int fi = sy * ci, fj = sx * cj;
       const i64 c = (i64)fi * F.W + fj;
       double h = 0.0;
-      if (fj > 0) h += (double)r[(c - 1) * Bp + nm.b];
-      if (fj < F.nx) h += (double)r[(c + 1) * Bp + nm.b];
-      if (fi > 0) h += (double)r[(c - F.W) * Bp + nm.b];
-      if (fi < F.ny) h += (double)r[(c + F.W) * Bp + nm.b];
-      if (fi > 0 && fj < F.nx) h += (double)r[(c - F.W + 1) * Bp + nm.b];
-      if (fi < F.ny && fj > 0) h += (double)r[(c + F.W - 1) * Bp + nm.b];
+      if (sx == 2) {
+        if (fj > 0) h += (double)r[(c - 1) * Bp + nm.b];
+        if (fj < F.nx) h += (double)r[(c + 1) * Bp + nm.b];
+      }
+      if (sy == 2) {
+        if (fi > 0) h += (double)r[(c - F.W) * Bp + nm.b];
+        if (fi < F.ny) h += (double)r[(c + F.W) * Bp + nm.b];
+      }
+      if (sx == 2 && sy == 2) {  // midpoints of the quad diagonals b-d
+        if (fi > 0 && fj < F.nx) h += (double)r[(c - F.W + 1) * Bp + nm.b];
+        if (fi < F.ny && fj > 0) h += (double)r[(c + F.W - 1) * Bp + nm.b];
+      }
       out = (double)r[c * Bp + nm.b] + 0.5 * h;
     }
     rc[(i64)I * Bp + nm.b] = (TV)out;
@@ -531,37 +544,47 @@ __global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, c
       continue;
     }
     const int fi = i / F.W, fj = i - fi * F.W;
-    const int ci = fi >> 1, cj = fj >> 1;
+    const int sx = coarsen_x(F, C), sy = coarsen_y(F, C);
+    const bool oi = sy == 2 && (fi & 1), oj = sx == 2 && (fj & 1);  // between two coarse rows / columns
+    const int ci = sy == 2 ? fi >> 1 : fi, cj = sx == 2 ? fj >> 1 : fj;
     const i64 c = (i64)ci * C.W + cj;
     double v;
-    if (!(fi & 1) && !(fj & 1))
+    if (!oi && !oj)
       v = (double)e[c * Bp + nm.b];
-    else if (!(fi & 1))
+    else if (!oi)
       v = 0.5 * ((double)e[c * Bp + nm.b] + (double)e[(c + 1) * Bp + nm.b]);
-    else if (!(fj & 1))
+    else if (!oj)
       v = 0.5 * ((double)e[c * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
-    else  // midpoint of the quad diagonal b-d
+    else  // midpoint of the quad diagonal b-d (full coarsening only)
       v = 0.5 * ((double)e[(c + 1) * Bp + nm.b] + (double)e[(c + C.W) * Bp + nm.b]);
     x[(i64)i * Bp + nm.b] = set ? (TV)v : (TV)((double)x[(i64)i * Bp + nm.b] + v);
   }
 }
 
-// per-element kappa of the coarse triangulation = mean of its 4 children (Galerkin for nested P1)
+// per-element kappa of the coarse triangulation.  Full coarsening (sx = sy = 2): mean of the 4 children
+// (Galerkin for nested P1).  Semi-coarsening: both coarse triangles of a cell take the mean of the 4 fine
+// triangles of the 2 fine cells it covers.
 __global__ __launch_bounds__(256) void mg_restrict_kappa_kernel(const double* __restrict__ kf, double* __restrict__ kc,
-                                                                 int nxc, int nyc, int Bv) {
+                                                                 int nxc, int nyc, int sx, int sy, int Bv) {
   const NodeMap nm = node_map(Bv);
-  const int mc = 2 * nxc * nyc, nxf = 2 * nxc;
+  const int mc = 2 * nxc * nyc, nxf = sx * nxc;
   for (int E = nm.node0; E < mc; E += nm.stride) {
     const int q = E >> 1, up = E & 1;
     const int I = q / nxc, J = q - I * nxc;
     // fine element id = 2*(row*nxf + col) + upper
     auto fe = [&](int r, int c, int u) { return (i64)(2 * ((i64)r * nxf + c) + u) * Bv + nm.b; };
     double s;
-    if (!up)
-      s = kf[fe(2 * I, 2 * J, 0)] + kf[fe(2 * I, 2 * J, 1)] + kf[fe(2 * I, 2 * J + 1, 0)] + kf[fe(2 * I + 1, 2 * J, 0)];
-    else
-      s = kf[fe(2 * I + 1, 2 * J + 1, 1)] + kf[fe(2 * I + 1, 2 * J + 1, 0)] + kf[fe(2 * I, 2 * J + 1, 1)] +
-          kf[fe(2 * I + 1, 2 * J, 1)];
+    if (sx == 2 && sy == 2) {
+      if (!up)
+        s = kf[fe(2 * I, 2 * J, 0)] + kf[fe(2 * I, 2 * J, 1)] + kf[fe(2 * I, 2 * J + 1, 0)] + kf[fe(2 * I + 1, 2 * J, 0)];
+      else
+        s = kf[fe(2 * I + 1, 2 * J + 1, 1)] + kf[fe(2 * I + 1, 2 * J + 1, 0)] + kf[fe(2 * I, 2 * J + 1, 1)] +
+            kf[fe(2 * I + 1, 2 * J, 1)];
+    } else if (sx == 2) {
+      s = kf[fe(I, 2 * J, 0)] + kf[fe(I, 2 * J, 1)] + kf[fe(I, 2 * J + 1, 0)] + kf[fe(I, 2 * J + 1, 1)];
+    } else {
+      s = kf[fe(2 * I, J, 0)] + kf[fe(2 * I, J, 1)] + kf[fe(2 * I + 1, J, 0)] + kf[fe(2 * I + 1, J, 1)];
+    }
     kc[(i64)E * Bv + nm.b] = 0.25 * s;
   }
 }
@@ -878,7 +901,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     if (l < last) {
       op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
-      if (strip_geom(L, H.Bp).use) {
+      if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
         constexpr int CW = 4;
         const int ncb = (C.W + 4 * CW - 1) / (4 * CW);
         int nrc = (4096 + ncb * (H.Bp / kWave) - 1) / (ncb * (H.Bp / kWave));
@@ -901,7 +924,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
     const StripGeom g = strip_geom(L, H.Bp);
-    if (g.use) {  // prolongate + correct + first post-sweep in one pass
+    if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
@@ -968,7 +991,11 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
   for (int l = 0; l < n_levels; ++l) {
     const diffhe_mg_level& s = levels[l];
     if (s.nx < 2 || s.ny < 2 || (s.nd != 3 && s.nd != 4) || !s.vals || !s.is_bc) return DIFFHE_E_BADARG;
-    if (l > 0 && (levels[l - 1].nx != 2 * s.nx || levels[l - 1].ny != 2 * s.ny)) return DIFFHE_E_BADARG;
+    if (l > 0) {  // each level halves the previous one in x, in y, or in both
+      const bool hx = levels[l - 1].nx == 2 * s.nx, hy = levels[l - 1].ny == 2 * s.ny;
+      const bool kx = levels[l - 1].nx == s.nx, ky = levels[l - 1].ny == s.ny;
+      if (!((hx && hy) || (hx && ky) || (kx && hy))) return DIFFHE_E_BADARG;
+    }
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
@@ -1223,10 +1250,11 @@ extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const
 }
 
 extern "C" int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse,
-                                             int ny_coarse, int Bv, void* stream) {
+                                             int ny_coarse, int sx, int sy, int Bv, void* stream) {
   if (!kappa_fine || !kappa_coarse || nx_coarse < 1 || ny_coarse < 1) return DIFFHE_E_BADARG;
+  if ((sx != 1 && sx != 2) || (sy != 1 && sy != 2) || (sx == 1 && sy == 1)) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
   hipLaunchKernelGGL(mg_restrict_kappa_kernel, node_grid(2 * nx_coarse * ny_coarse, Bv), dim3(256), 0,
-                     (hipStream_t)stream, kappa_fine, kappa_coarse, nx_coarse, ny_coarse, Bv);
+                     (hipStream_t)stream, kappa_fine, kappa_coarse, nx_coarse, ny_coarse, sx, sy, Bv);
   return diffhe::check_launch();
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
     "diffhe_lattice_cg_step": (_I, [_LV, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "diffhe_lattice_bilinear": (_I, [_LV, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_lattice_apply_shared": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
-    "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _P]),
+    "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "diffhe_to_node_major": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),

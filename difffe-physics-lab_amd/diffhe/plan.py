@@ -164,6 +164,25 @@ def build_dia_pattern(nx: int, ny: int):
     return dict(We=7, cols=ell_cols.reshape(7, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib)
 
 
+def coarsening_step(nodes2d: np.ndarray):
+    """(row step, column step) for the next multigrid level of a lattice with node array (ny+1, nx+1, 2),
+    or None to stop.  While the cells are anisotropic (mean edge ratio > 1.6) only the direction of the
+    SHORT edges -- the strongly coupled one, which point smoothing cannot handle -- is coarsened
+    (semi-coarsening); otherwise both are halved.  A direction is only halved while it stays even and >= 4."""
+    ny, nx = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
+    hx = float(np.mean(np.linalg.norm(nodes2d[:, 1:] - nodes2d[:, :-1], axis=2)))
+    hy = float(np.mean(np.linalg.norm(nodes2d[1:, :] - nodes2d[:-1, :], axis=2)))
+    can_x = nx % 2 == 0 and nx >= 4
+    can_y = ny % 2 == 0 and ny >= 4
+    if hy * 1.6 < hx:                      # short vertical edges: coarsen rows (y) only
+        return (2, 1) if can_y else None
+    if hx * 1.6 < hy:
+        return (1, 2) if can_x else None
+    if can_x and can_y:
+        return (2, 2)
+    return None
+
+
 class LatticeLevel:
     """One level of the multigrid hierarchy of a lattice mesh: geometry, element integrals
     and gather lists on the device.  Level l uses every 2^l-th node of the fine mesh."""
@@ -255,12 +274,12 @@ class SolvePlan:
             nx, ny = lat
             nodes2d = nodes.reshape(ny + 1, nx + 1, 2)
             bc2d = is_bc.reshape(ny + 1, nx + 1)
-            while True:
+            while len(self.levels) < 16:
                 self.levels.append(LatticeLevel(nodes2d, bc2d, device, with_load_matrix=not self.levels))
-                ny_l, nx_l = nodes2d.shape[0] - 1, nodes2d.shape[1] - 1
-                if nx_l % 2 or ny_l % 2 or min(nx_l, ny_l) < 4 or len(self.levels) >= 16:
+                step = coarsening_step(nodes2d)
+                if step is None:
                     break
-                nodes2d, bc2d = nodes2d[::2, ::2], bc2d[::2, ::2]
+                nodes2d, bc2d = nodes2d[::step[0], ::step[1]], bc2d[::step[0], ::step[1]]
 
         # --- general ELL path: built eagerly for general meshes, lazily for lattice meshes (only
         # method="ell" needs it there; the pattern build costs ~20 s of numpy at 1024^2) ------------

@@ -210,7 +210,9 @@ class _Engine:
         for li, lev in enumerate(p.levels):
             if li > 0 and mode in (K_ELEM, K_SAMPLE_ELEM):   # coarse kappa = mean of the 4 children
                 kc = torch.empty((lev.m, Bv), dtype=torch.float64, device=p.device)
-                _hip.check(L.diffhe_lattice_restrict_kappa(_hip.ptr(kl), _hip.ptr(kc), lev.nx, lev.ny, Bv, st),
+                prev = p.levels[li - 1]
+                _hip.check(L.diffhe_lattice_restrict_kappa(_hip.ptr(kl), _hip.ptr(kc), lev.nx, lev.ny,
+                                                           prev.nx // lev.nx, prev.ny // lev.ny, Bv, st),
                            "diffhe_lattice_restrict_kappa")
                 kl = kc
             v = torch.empty((lev.nd, lev.n, Bv), dtype=torch.float64, device=p.device)

@@ -153,7 +153,8 @@ int diffhe_ell_apply(const double* vals, const int* cols, const double* x, doubl
  * Lattice fast path: meshes with the connectivity of FEMesh.rectangle (mesh.py:100-105).
  * Operator = symmetric diagonals D0 (i,i), D1 (i,i+1), D2 (i,i+nx+1), D3 (i,i+nx; only when
  * nd == 4), values (nd, n, Bv) produced by diffhe_ell_assemble_rows with
- * store_slot = {0,1,2,3|-1,-1,-1,-1}.  Level l+1 is the 2:1 coarsening of level l.
+ * store_slot = {0,1,2,3|-1,-1,-1,-1}.  Level l+1 halves level l in x, in y (semi-coarsening of
+ * anisotropic meshes) or in both.
  * ---------------------------------------------------------------------------- */
 typedef struct diffhe_mg_level {
   int nx, ny;                  /* elements per direction; n = (nx+1)*(ny+1) */
@@ -216,9 +217,10 @@ int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* 
 int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, const double* x, const double* sub,
                                 int sub_B, const double* sub_scale, const unsigned char* mask, double* y, int Bp,
                                 void* stream);
-/* kappa_coarse[E] = mean of the 4 children of coarse triangle E; arrays (m, Bv). */
+/* kappa of the coarse triangulation, arrays (m, Bv); sx, sy in {1, 2} = coarsening factor per direction.
+ * Full coarsening: mean of the 4 children of each coarse triangle; semi: mean over the 2 covered fine cells. */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
-                                  int Bv, void* stream);
+                                  int sx, int sy, int Bv, void* stream);
 
 /* dL/dkappa contraction (reverse of solver.py:89-92 / :137-140, Appendix A step 2):
  *   dk[e,b] = - sum_{p,q} lambda[elem_p,b] * k0[p*npe+q, e] * (u[elem_q,b] + g[elem_q])

@@ -651,3 +651,26 @@ def test_fused_cg_step_kernel_vs_reference_formulas():
             assert rel_err(p_out.double().cpu().numpy(), p_ref) < 1e-14
             assert rel_err(x.cpu().numpy(), x_ref) < 1e-14
             assert rel_err(Ap.cpu().numpy(), Ap_ref) < 1e-13
+
+
+@pytest.mark.parametrize("nx,ny,xr", [(96, 96, (0.0, 8.0)), (256, 32, (0.0, 1.0)), (40, 160, (0.0, 1.0))])
+def test_anisotropic_lattices_semi_coarsening(nx, ny, xr):
+    """Elongated cells: levels are coarsened in the strongly coupled direction only until the cells are
+    isotropic, so the iteration count stays at the isotropic level; values and gradients match the oracle."""
+    mesh = FEMesh.rectangle(nx, ny, xr, (0.0, 1.0), 0.05)
+    nodes, el, bn, bv = arrays(mesh)
+    rng = np.random.default_rng(17)
+    B = 3
+    kap = np.exp(0.3 * rng.standard_normal((B, mesh.n_elements)))        # per-element: kappa restriction too
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    kt = torch.from_numpy(kap).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(torch.from_numpy(f))
+    (u ** 2).sum().backward()
+    levels = [(lv.nx, lv.ny) for lv in get_plan(mesh, torch.device("cuda", 0)).levels]
+    assert any(a[0] == b[0] or a[1] == b[1] for a, b in zip(levels, levels[1:])), levels   # a semi step exists
+    assert solver.last_info.iterations <= 16, (solver.last_info, levels)
+    for b in range(B):
+        uo, dko, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
+        assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+        assert rel_err(kt.grad[b].numpy(), dko) < RTOL_GRAD

@@ -244,3 +244,15 @@ def test_custom_ops_are_registered_with_shape_inference():
         assert u.shape == (6, 25)
         gk, gf = torch.ops.diffhe.fe_solve_backward(u, tok, True, False, kb, f1)
         assert gk.shape == (6,) and gf.numel() == 0
+
+
+def test_coarsening_step_rules():
+    from diffhe.plan import coarsening_step
+    grid = lambda nx, ny, lx, ly: FEMesh.rectangle(nx, ny, (0.0, lx), (0.0, ly)).nodes.numpy().reshape(ny + 1, nx + 1, 2)  # noqa: E731
+    assert coarsening_step(grid(64, 64, 1.0, 1.0)) == (2, 2)
+    assert coarsening_step(grid(64, 64, 8.0, 1.0)) == (2, 1)      # short vertical edges: halve the rows only
+    assert coarsening_step(grid(64, 64, 1.0, 8.0)) == (1, 2)
+    assert coarsening_step(grid(512, 64, 1.0, 1.0)) == (1, 2)     # short horizontal edges: halve the columns
+    assert coarsening_step(grid(6, 6, 1.0, 1.0)) == (2, 2)
+    assert coarsening_step(grid(3, 3, 1.0, 1.0)) is None          # odd: stop
+    assert coarsening_step(grid(64, 5, 8.0, 1.0)) is None         # would need the rows, which do not halve
