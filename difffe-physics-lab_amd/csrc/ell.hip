@@ -475,6 +475,226 @@ __global__ __launch_bounds__(256) void to_sample_major_kernel(const double* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Aggregation multigrid for the general path (diffhe/amg.py builds the batch-shared hierarchy)
+// ---------------------------------------------------------------------------------------
+// coarse values = P^T A P for piecewise-constant P: plain sums of fine entries (per sample)
+__global__ __launch_bounds__(256) void ell_galerkin_kernel(const double* __restrict__ vals_f,
+                                                            const int* __restrict__ ent_ptr,
+                                                            const int* __restrict__ contrib,
+                                                            double* __restrict__ vals_c, int nc, int Wc, int Bv) {
+  const NodeMap nm = node_map(Bv);
+  if (nm.b >= Bv) return;
+  for (int I = nm.node0; I < nc; I += nm.stride)
+    for (int k = 0; k < Wc; ++k) {
+      const i64 ent = (i64)k * nc + I;
+      double v = 0.0;
+      for (int c = ent_ptr[ent]; c < ent_ptr[ent + 1]; ++c) v += vals_f[(i64)contrib[c] * Bv + nm.b];
+      vals_c[ent * Bv + nm.b] = v;
+    }
+}
+
+// weighted Jacobi: xout = xin + omega (b - A xin) / D (xin == NULL: from zero); optional partial of b.xout
+__global__ __launch_bounds__(256) void ell_jacobi_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
+                                                          const double* __restrict__ bvec,
+                                                          const double* __restrict__ xin, double* __restrict__ xout,
+                                                          double omega, double* __restrict__ part, int n, int W, int Bp,
+                                                          int Bv) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  double s = 0.0;
+  if (ok)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const i64 o = (i64)i * Bp + nm.b;
+      const double d = vals[(i64)i * Bv + vb];
+      const double bi = bvec[o];
+      double xo;
+      if (xin) {
+        double acc = bi;
+        for (int k = 0; k < W; ++k) {
+          const i64 ent = (i64)k * n + i;
+          acc -= vals[ent * Bv + vb] * xin[(i64)cols[ent] * Bp + nm.b];
+        }
+        xo = xin[o] + omega * acc / d;
+      } else {
+        xo = omega * bi / d;
+      }
+      xout[o] = xo;
+      s += bi * xo;
+    }
+  if (part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double t = block_sum_per_sample(s, Bp, lds);
+    if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part[(i64)blockIdx.x * Bp + nm.b] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void ell_residual_out_kernel(const double* __restrict__ vals,
+                                                                const int* __restrict__ cols,
+                                                                const double* __restrict__ bvec,
+                                                                const double* __restrict__ x, double* __restrict__ r,
+                                                                int n, int W, int Bp, int Bv) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  const int vb = Bv == 1 ? 0 : nm.b;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    double acc = bvec[(i64)i * Bp + nm.b];
+    for (int k = 0; k < W; ++k) {
+      const i64 ent = (i64)k * n + i;
+      acc -= vals[ent * Bv + vb] * x[(i64)cols[ent] * Bp + nm.b];
+    }
+    r[(i64)i * Bp + nm.b] = acc;
+  }
+}
+
+// rc[I] = sum of r over the members of aggregate I (fixed order)
+__global__ __launch_bounds__(256) void agg_restrict_kernel(const double* __restrict__ r, const int* __restrict__ agg_ptr,
+                                                            const int* __restrict__ members, double* __restrict__ rc,
+                                                            int nc, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  for (int I = nm.node0; I < nc; I += nm.stride) {
+    double s = 0.0;
+    for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s += r[(i64)members[c] * Bp + nm.b];
+    rc[(i64)I * Bp + nm.b] = s;
+  }
+}
+
+// x[i] += scale * e[agg[i]]
+__global__ __launch_bounds__(256) void agg_prolong_add_kernel(const double* __restrict__ e, const int* __restrict__ agg,
+                                                               double* __restrict__ x, double scale, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const int I = agg[i];
+    if (I >= 0) x[(i64)i * Bp + nm.b] += scale * e[(i64)I * Bp + nm.b];
+  }
+}
+
+// x += alpha p ; r -= alpha Ap ; partial r.r
+__global__ __launch_bounds__(256) void amg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
+                                                          const double* __restrict__ alpha, double* __restrict__ x,
+                                                          double* __restrict__ r, double* __restrict__ part_rr, int n,
+                                                          int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  double s = 0.0;
+  if (ok) {
+    const double a = alpha[nm.b];
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const i64 o = (i64)i * Bp + nm.b;
+      x[o] += a * p[o];
+      const double ri = r[o] - a * Ap[o];
+      r[o] = ri;
+      s += ri * ri;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t = block_sum_per_sample(s, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_rr[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+// x = 0 ; r = b ; partial b.b
+__global__ __launch_bounds__(256) void amg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
+                                                        double* __restrict__ r, double* __restrict__ p,
+                                                        double* __restrict__ part_bb, int n, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const NodeMap nm = node_map(Bp);
+  const bool ok = nm.b < Bp;
+  double s = 0.0;
+  if (ok)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const i64 o = (i64)i * Bp + nm.b;
+      const double bi = bvec[o];
+      x[o] = 0.0; r[o] = bi; p[o] = 0.0;
+      s += bi * bi;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double t = block_sum_per_sample(s, Bp, lds);
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_bb[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+constexpr int kAmgMaxLevels = 16;
+
+struct AmgHier {
+  diffhe_amg_level lev[kAmgMaxLevels];
+  int nl, Bv, Bp, n_coarse, gamma;
+  double w0, w1, scale;
+  double *xa[kAmgMaxLevels], *xb[kAmgMaxLevels], *res[kAmgMaxLevels], *rhs[kAmgMaxLevels];
+};
+
+#define ALAUNCH(kernel, n_, ...) \
+  hipLaunchKernelGGL(kernel, diffhe::node_grid((n_), H.Bp), dim3(256), 0, st, __VA_ARGS__)
+
+// x ~= A_l^{-1} rhs from a zero guess: V(2,2) weighted Jacobi, `gamma` coarse corrections per level
+// (gamma = 2: W-cycle -- affordable because aggregation coarsens by ~10x -- compensates the weak
+// piecewise-constant interpolation).  Returns the buffer holding the result.
+double* amg_cycle(const AmgHier& H, int l, const double* rhs, double* rz_part, hipStream_t st) {
+  const diffhe_amg_level& L = H.lev[l];
+  double* a = H.xa[l];
+  double* b2 = H.xb[l];
+  const bool last = (l == H.nl - 1);
+  const int pre = last ? H.n_coarse : 2;
+  for (int s = 0; s < pre; ++s) {
+    const double w = (s & 1) ? H.w1 : H.w0;
+    const bool fin = last && s == pre - 1;
+    if (s == 0) {
+      ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)nullptr, a, w, fin ? rz_part : (double*)nullptr,
+              L.n, L.W, H.Bp, H.Bv);
+    } else {
+      ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, b2, w, fin ? rz_part : (double*)nullptr, L.n,
+              L.W, H.Bp, H.Bv);
+      double* t = a; a = b2; b2 = t;
+    }
+  }
+  if (last) return a;
+  const diffhe_amg_level& C = H.lev[l + 1];
+  const int cycles = (l + 1 == H.nl - 1) ? 1 : H.gamma;  // the last level is "solved": one visit is enough
+  for (int g = 0; g < cycles; ++g) {
+    ALAUNCH(ell_residual_out_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, H.res[l], L.n, L.W, H.Bp, H.Bv);
+    ALAUNCH(agg_restrict_kernel, C.n, (const double*)H.res[l], L.agg_ptr, L.agg_members, H.rhs[l + 1], C.n, H.Bp);
+    const double* ec = amg_cycle(H, l + 1, H.rhs[l + 1], nullptr, st);
+    ALAUNCH(agg_prolong_add_kernel, L.n, ec, L.agg, a, H.scale, L.n, H.Bp);
+  }
+  for (int s = 0; s < 2; ++s) {
+    const double w = (s & 1) ? H.w0 : H.w1;  // reverse order: symmetric cycle
+    ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, b2, w,
+            (l == 0 && s == 1) ? rz_part : (double*)nullptr, L.n, L.W, H.Bp, H.Bv);
+    double* t = a; a = b2; b2 = t;
+  }
+  return a;
+}
+
+long long amg_carve(AmgHier& H, double* work) {
+  long long off = 0;
+  auto take = [&](long long cnt) { double* q = work ? work + off : nullptr; off += (cnt + 7) & ~7LL; return q; };
+  for (int l = 0; l < H.nl; ++l) {
+    const long long nb = (long long)H.lev[l].n * H.Bp;
+    H.xa[l] = take(nb);
+    H.xb[l] = take(nb);
+    H.res[l] = take(nb);
+    H.rhs[l] = l > 0 ? take(nb) : nullptr;
+  }
+  return off;
+}
+
+int amg_fill(AmgHier& H, const diffhe_amg_level* levels, int n_levels, int Bv, int Bp) {
+  if (!levels || n_levels < 1 || n_levels > kAmgMaxLevels) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
+  for (int l = 0; l < n_levels; ++l) {
+    const diffhe_amg_level& s = levels[l];
+    if (s.n < 1 || s.W < 1 || !s.vals || !s.cols) return DIFFHE_E_BADARG;
+    if (l < n_levels - 1 && (!s.agg || !s.agg_ptr || !s.agg_members)) return DIFFHE_E_BADARG;
+    H.lev[l] = s;
+  }
+  H.nl = n_levels; H.Bv = Bv; H.Bp = Bp;
+  return DIFFHE_OK;
+}
+
 inline int cg_blocks(int n, int Bp) { return (int)node_grid(n, Bp).x; }
 
 }  // namespace
@@ -613,6 +833,91 @@ extern "C" int diffhe_ell_apply(const double* vals, const int* cols, const doubl
   hipLaunchKernelGGL(cg_spmv_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, vals, cols, x, y,
                      part, n, W, Bp, Bv);
   return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, double* vals_coarse,
+                                   int n_coarse, int W_coarse, int Bv, void* stream) {
+  if (!vals_fine || !ent_ptr || !contrib || !vals_coarse || n_coarse < 1 || W_coarse < 1) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  hipLaunchKernelGGL(ell_galerkin_kernel, diffhe::node_grid(n_coarse, Bv), dim3(256), 0, (hipStream_t)stream, vals_fine,
+                     ent_ptr, contrib, vals_coarse, n_coarse, W_coarse, Bv);
+  return diffhe::check_launch();
+}
+
+extern "C" long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* levels, int n_levels, int Bp) {
+  AmgHier H;
+  if (amg_fill(H, levels, n_levels, 1, Bp)) return -1;
+  const long long nb = (long long)H.lev[0].n * Bp;
+  const long long nblk = cg_blocks(H.lev[0].n, Bp);
+  return amg_carve(H, nullptr) + 3 * nb + 3 * nblk * Bp + 16LL * Bp + 64;
+}
+
+extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x,
+                                        int Bp, double tol, int max_iter, int n_coarse, int gamma, double scale,
+                                        double* work, double* relres, int* iters, int* status_host, void* stream) {
+  if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0 || n_coarse < 1 || gamma < 1)
+    return DIFFHE_E_BADARG;
+  AmgHier H;
+  int rc = amg_fill(H, levels, n_levels, Bv, Bp);
+  if (rc) return rc;
+  H.n_coarse = n_coarse; H.gamma = gamma; H.scale = scale;
+  H.w0 = 0.56; H.w1 = 1.39;  // Chebyshev weights for the interval [0.5, 2] of D^-1 A
+  hipStream_t st = (hipStream_t)stream;
+  const diffhe_amg_level& L0 = H.lev[0];
+  const int n = L0.n, W = L0.W;
+  const dim3 grid = diffhe::node_grid(n, Bp);
+  const int nblk = grid.x;
+  const long long NB = (long long)n * Bp;
+  double* w = work + amg_carve(H, work);
+  double* r = w;
+  double* p = r + NB;
+  double* Ap = p + NB;
+  double* partA = Ap + NB;
+  double* partB = partA + (long long)nblk * Bp;
+  double* partC = partB + (long long)nblk * Bp;
+  double* sc = partC + (long long)nblk * Bp;
+  CgScalars S;
+  S.rz = sc; S.pAp = sc + Bp; S.alpha = sc + 2 * Bp; S.beta = sc + 3 * Bp; S.bb = sc + 4 * Bp;
+  S.tol2 = sc + 5 * Bp; S.rr = sc + 6 * Bp;
+  S.active = (int*)(sc + 7 * Bp);
+  S.iters = iters;
+  S.n_active = (int*)(sc + 8 * Bp);
+  const dim3 sgrid((Bp + 63) / 64);
+
+  hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, p, partC, n, Bp);
+  const double* z = amg_cycle(H, 0, r, partB, st);
+  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, (const double*)partB, (const double*)partC,
+                     nblk, Bp, tol, S, relres);
+  hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, (const double*)S.beta, p, n, Bp);  // beta = 0: p = z
+  rc = diffhe::check_launch();
+  if (rc) return rc;
+  int it = 0, n_active = -1;
+  while (it < max_iter) {
+    hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, (const double*)p, Ap, partA, n, W, Bp, Bv);
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, (const double*)partA,
+                       (const double*)nullptr, nblk, Bp, tol, S, relres);
+    hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
+                       (const double*)S.alpha, x, r, partC, n, Bp);
+    z = amg_cycle(H, 0, r, partB, st);
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, (const double*)partB, (const double*)partC,
+                       nblk, Bp, tol, S, relres);
+    hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, (const double*)S.beta, p, n, Bp);
+    ++it;
+    rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (rc) return rc;
+    rc = diffhe::check(hipStreamSynchronize(st));
+    if (rc) return rc;
+    n_active = status_host[2];
+    if (n_active == 0) break;
+  }
+  hipLaunchKernelGGL(residual_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, b, (const double*)x, partA, n, W, Bp, Bv);
+  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_RELRES, (const double*)partA,
+                     (const double*)nullptr, nblk, Bp, tol, S, relres);
+  rc = diffhe::check_launch();
+  if (rc) return rc;
+  status_host[0] = it;
+  status_host[1] = n_active < 0 ? 0 : n_active;
+  return DIFFHE_OK;
 }
 
 extern "C" int diffhe_grad_kappa_blocks(int m, int Bp) { return (int)diffhe::node_grid(m, Bp).x; }

@@ -22,6 +22,14 @@ class MgLevel(C.Structure):
 
 _LV = C.POINTER(MgLevel)
 
+
+class AmgLevel(C.Structure):
+    """struct diffhe_amg_level (include/diffhe_hip.h)."""
+    _fields_ = [("n", _I), ("W", _I), ("vals", _P), ("cols", _P), ("agg", _P), ("agg_ptr", _P), ("agg_members", _P)]
+
+
+_AV = C.POINTER(AmgLevel)
+
 # name -> (restype, argtypes); must list every symbol of include/diffhe_hip.h
 SIGNATURES = {
     "diffhe_abi_version": (_I, []),
@@ -36,6 +44,9 @@ SIGNATURES = {
     "diffhe_ell_spmv_shared": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "diffhe_cg_workspace_doubles": (_L, [_I, _I]),
     "diffhe_ell_cg_solve": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
+    "diffhe_ell_galerkin": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "diffhe_ell_amg_workspace_doubles": (_L, [_AV, _I, _I]),
+    "diffhe_ell_amg_pcg_solve": (_I, [_AV, _I, _I, _P, _P, _I, _D, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pcg_workspace_doubles": (_L, [_LV, _I, _I]),
     "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P, _P,

@@ -1,0 +1,151 @@
+"""Aggregation hierarchy for general (unstructured) P1 meshes -- host side.
+
+The general ELL path has no geometric hierarchy to lean on, so its multigrid preconditioner is
+algebraic: nodes are grouped into aggregates (roots = a distance-2 maximal independent set of the
+mesh graph, every other node joins an adjacent aggregate), the prolongation is piecewise constant,
+and the coarse operators are the Galerkin products P^T A P -- which for piecewise-constant P are
+plain sums of fine-matrix entries, so they are rebuilt PER SAMPLE on the device from gather lists
+(`diffhe_ell_galerkin`) while the aggregates and patterns, computed here once per mesh with
+vectorised numpy, are shared by the whole batch.  Dirichlet nodes belong to no aggregate (their
+rows are identity rows and their residual is zero).
+
+Nothing here has a counterpart in the reference (it solves with a dense LU, solver.py:174).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+
+def aggregate(cols: np.ndarray, active: np.ndarray, seed: int = 0) -> np.ndarray:
+    """Node -> aggregate id (or -1 for inactive nodes) for the graph given by ELL columns
+    `cols` (W, n) (slot 0 = the node itself, unused slots point at the node itself).
+
+    Roots are picked as strict priority maxima within graph distance 2 (Luby rounds), so two
+    roots are never adjacent or share a neighbour; each remaining node joins the aggregate of an
+    adjacent root, else of an adjacent already-aggregated node; isolated leftovers become singletons.
+    Deterministic for a given seed.
+    """
+    W, n = cols.shape
+    rng = np.random.default_rng(seed)
+    prio = rng.permutation(n).astype(np.float64) + 1.0
+    prio[~active] = -np.inf
+    state = np.zeros(n, dtype=np.int8)            # 0 undecided, 1 root, 2 within distance 2 of a root
+    state[~active] = 2
+    idx_all = np.arange(n)
+    while True:
+        cand = state == 0
+        if not cand.any():
+            break
+        pc = np.where(cand, prio, -np.inf)
+        m1 = pc[cols].max(axis=0)                  # max over the closed neighbourhood
+        m2 = m1[cols].max(axis=0)                  # ... over distance 2
+        new_root = cand & (pc >= m2)
+        state[new_root] = 1
+        near1 = new_root[cols].any(axis=0)
+        near2 = near1[cols].any(axis=0)
+        state[near2 & (state == 0)] = 2
+    roots = np.nonzero(state == 1)[0]
+    agg = np.full(n, -1, dtype=np.int64)
+    agg[roots] = np.arange(len(roots))
+    # distance-1 neighbours of a root join it (a node is adjacent to at most one root)
+    nb = agg[cols]                                 # (W, n) aggregate of each neighbour, -1 if none
+    join = nb.max(axis=0)
+    take = active & (agg < 0) & (join >= 0)
+    agg[take] = join[take]
+    # the rest (distance 2 from every root) joins any adjacent aggregate; repeat until stable
+    for _ in range(8):
+        left = active & (agg < 0)
+        if not left.any():
+            break
+        join = agg[cols].max(axis=0)
+        take = left & (join >= 0)
+        if not take.any():
+            break
+        agg[take] = join[take]
+    left = np.nonzero(active & (agg < 0))[0]       # disconnected leftovers: singletons
+    if len(left):
+        base = int(agg.max()) + 1
+        agg[left] = base + np.arange(len(left))
+    del idx_all
+    return agg
+
+
+def coarse_pattern(cols: np.ndarray, agg: np.ndarray):
+    """Galerkin gather lists for piecewise-constant aggregation.
+
+    Returns dict(n, W, cols (W,n) i32, ent_ptr (W*n+1) i32, contrib i32) for the coarse level:
+    coarse entry (I, slot) at slot*n + I sums the fine entries listed in contrib[ent_ptr[.]:ent_ptr[.+1]]
+    (fine entry index = k*n_fine + i).  Slot 0 is the diagonal."""
+    Wf, nf = cols.shape
+    nc = int(agg.max()) + 1
+    k_idx, i_idx = np.meshgrid(np.arange(Wf, dtype=np.int64), np.arange(nf, dtype=np.int64), indexing="ij")
+    j_idx = cols.astype(np.int64)
+    real = (k_idx == 0) | (j_idx != i_idx)         # drop the padding slots (they point at the row itself)
+    I = agg[i_idx]
+    J = agg[j_idx]
+    keep = real & (I >= 0) & (J >= 0)
+    I, J = I[keep], J[keep]
+    fine_entry = (k_idx * nf + i_idx)[keep]
+    # coarse entries: unique (I, J), diagonal first within each row
+    rows_all = np.concatenate([np.arange(nc, dtype=np.int64), I])
+    cols_all = np.concatenate([np.arange(nc, dtype=np.int64), J])
+    offd = (rows_all != cols_all).astype(np.int64)
+    key = (rows_all * 2 + offd) * nc + cols_all
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    new = np.ones(len(ks), dtype=bool)
+    new[1:] = ks[1:] != ks[:-1]
+    entry_id = np.cumsum(new) - 1
+    ent_rows = rows_all[order][new]
+    ent_cols = cols_all[order][new]
+    row_start = np.searchsorted(ent_rows, np.arange(nc))
+    slot = np.arange(len(ent_rows)) - row_start[ent_rows]
+    W = int(slot.max()) + 1
+    ccols = np.tile(np.arange(nc, dtype=np.int32), W)
+    cidx = slot * nc + ent_rows
+    ccols[cidx] = ent_cols.astype(np.int32)
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.arange(len(order))
+    contrib_entry = cidx[entry_id[inv[nc:]]]
+    corder = np.argsort(contrib_entry, kind="stable")
+    contrib = fine_entry[corder]
+    ent_ptr = np.zeros(W * nc + 1, dtype=np.int64)
+    np.cumsum(np.bincount(contrib_entry, minlength=W * nc), out=ent_ptr[1:])
+    if ent_ptr[-1] >= 2 ** 31 or Wf * nf >= 2 ** 31:
+        raise ValueError("mesh too large for int32 gather lists")
+    return dict(n=nc, W=W, cols=ccols.reshape(W, nc), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib.astype(np.int32))
+
+
+def members_csr(agg: np.ndarray, nc: int):
+    """CSR of aggregate members: (ptr (nc+1) i32, members i32 sorted by aggregate then node id)."""
+    act = np.nonzero(agg >= 0)[0]
+    order = np.argsort(agg[act], kind="stable")
+    members = act[order].astype(np.int32)
+    ptr = np.zeros(nc + 1, dtype=np.int64)
+    np.cumsum(np.bincount(agg[act], minlength=nc), out=ptr[1:])
+    return ptr.astype(np.int32), members
+
+
+def build_hierarchy(cols: np.ndarray, is_bc: np.ndarray, min_coarse: int = 64, max_levels: int = 12) -> List[Dict]:
+    """Levels below the fine one: each dict holds the aggregation of the PREVIOUS level (agg, agg_ptr,
+    agg_members) and the pattern / Galerkin lists of this level (n, W, cols, ent_ptr, contrib)."""
+    levels: List[Dict] = []
+    active = ~is_bc.astype(bool)
+    cur_cols = cols
+    while len(levels) < max_levels - 1:
+        n_active = int(active.sum())
+        if n_active <= min_coarse:
+            break
+        agg = aggregate(cur_cols, active, seed=len(levels))
+        nc = int(agg.max()) + 1
+        if nc >= 0.7 * n_active:                   # not coarsening any more (e.g. disconnected graph)
+            break
+        pat = coarse_pattern(cur_cols, agg)
+        ptr, members = members_csr(agg, nc)
+        pat.update(agg=agg.astype(np.int32), agg_ptr=ptr, agg_members=members)
+        levels.append(pat)
+        cur_cols = pat["cols"]
+        active = np.ones(nc, dtype=bool)
+    return levels

@@ -316,6 +316,19 @@ class SolvePlan:
                    "diffhe_ell_assemble_rows(M)")
         self._ell_ready = True
 
+    def ensure_amg(self):
+        """Aggregation hierarchy of the general path (diffhe/amg.py), uploaded once per mesh."""
+        if getattr(self, "amg_levels", None) is not None:
+            return
+        from .amg import build_hierarchy
+        self.ensure_ell()
+        device = self.device
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        host = build_hierarchy(self.cols.cpu().numpy(), self.is_bc.cpu().numpy())
+        self.amg_levels = [dict(n=lv["n"], W=lv["W"], cols=dev(lv["cols"]), ent_ptr=dev(lv["ent_ptr"]),
+                                contrib=dev(lv["contrib"]), agg=dev(lv["agg"]), agg_ptr=dev(lv["agg_ptr"]),
+                                agg_members=dev(lv["agg_members"])) for lv in host]
+
 
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream

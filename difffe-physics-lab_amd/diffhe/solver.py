@@ -257,6 +257,42 @@ class _Engine:
         st = p.pinned_status
         return x, int(st[0]), int(st[1]), relres
 
+    # -- general path with the aggregation-multigrid preconditioner ---------------------------------
+    def amg_setup(self, vals, Bv):
+        """Per-solve coarse operators (Galerkin sums of the fine values) + the level descriptor array."""
+        p, L = self.p, self.L
+        st = _stream(p.device)
+        chain = [dict(n=p.n, W=p.W, vals=vals, cols=p.cols)]
+        for lv in p.amg_levels:
+            vc = torch.empty((lv["W"], lv["n"], Bv), dtype=torch.float64, device=p.device)
+            _hip.check(L.diffhe_ell_galerkin(_hip.ptr(chain[-1]["vals"]), _hip.ptr(lv["ent_ptr"]), _hip.ptr(lv["contrib"]),
+                                             _hip.ptr(vc), lv["n"], lv["W"], Bv, st), "diffhe_ell_galerkin")
+            chain[-1].update(agg=lv["agg"], agg_ptr=lv["agg_ptr"], agg_members=lv["agg_members"])
+            chain.append(dict(n=lv["n"], W=lv["W"], vals=vc, cols=lv["cols"]))
+        arr = (_hip.AmgLevel * len(chain))()
+        for i, lv in enumerate(chain):
+            arr[i].n, arr[i].W = lv["n"], lv["W"]
+            arr[i].vals, arr[i].cols = lv["vals"].data_ptr(), lv["cols"].data_ptr()
+            if "agg" in lv:
+                arr[i].agg, arr[i].agg_ptr = lv["agg"].data_ptr(), lv["agg_ptr"].data_ptr()
+                arr[i].agg_members = lv["agg_members"].data_ptr()
+        return arr, chain      # keep `chain` alive: it owns the coarse value tensors
+
+    def amg_pcg(self, amg, rhs, Bp, Bv, opts):
+        p, L = self.p, self.L
+        arr, chain = amg
+        nl = len(chain)
+        x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        work = torch.empty(L.diffhe_ell_amg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
+        relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        _hip.check(L.diffhe_ell_amg_pcg_solve(arr, nl, Bv, _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
+                                              min(self.max_iter, 2000), int(opts["n_coarse"]), int(opts["gamma"]),
+                                              float(opts["scale"]), _hip.ptr(work), _hip.ptr(relres), _hip.ptr(iters),
+                                              _hip.ptr(p.pinned_status), _stream(p.device)), "diffhe_ell_amg_pcg_solve")
+        st = p.pinned_status
+        return x, int(st[0]), int(st[1]), relres
+
     def grad_kappa_factored(self, vals, lift, lam, x, Bp):
         """dL/dkappa_b = -lam^T K_1 u for a batch-shared (factored) lattice operator in one strip pass:
         lam^T (A_1 x + K_1[free,bc] g).  Returns None below the strip-kernel threshold."""
@@ -319,7 +355,7 @@ def _solve_forward(solver, kappa, f):
                                           _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
                    "diffhe_chain1d_solve")
         ctx.saved = (kdev, ksb, kse, u)
-    elif plan.is_lattice and solver.method != "ell":
+    elif plan.is_lattice and solver.method == "auto":
         info.path = "lattice-mgpcg"
         Bp = padded_batch(B)
         vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp)
@@ -335,14 +371,23 @@ def _solve_forward(solver, kappa, f):
         ctx.vals32 = vals32
         ctx.lift = lift if Bv == 1 else None
     else:
-        info.path = "ell-pcg"
         plan.ensure_ell()
         Bp = padded_batch(B)
         kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
         vals, lift = eng.assemble(kdev, kse, ksb, Bv)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp)
-        x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
+        ctx.amg = None
+        if solver.method != "ell-jacobi":
+            plan.ensure_amg()
+            if plan.amg_levels:                      # at least one coarse level: aggregation-AMG PCG
+                ctx.amg = eng.amg_setup(vals, Bv)
+        if ctx.amg is not None:
+            info.path = "ell-amgpcg"
+            x, its, bad, relres = eng.amg_pcg(ctx.amg, rhs, Bp, Bv, solver.amg)
+        else:
+            info.path = "ell-pcg"
+            x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
         u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
@@ -517,9 +562,14 @@ class DifferentiableFESolver(nn.Module):
             self._kappa = kappa.to(dtype=torch.float64)                  # reference solver.py:38-39
         if assembly not in ("gather", "atomic"):
             raise ValueError(f"Unknown assembly: {assembly!r}")
-        if method not in ("auto", "ell"):
+        if method not in ("auto", "ell", "ell-jacobi"):
             raise ValueError(f"Unknown method: {method!r}")
-        self.method = method      # "ell" forces the general path on lattice meshes
+        # "ell": general path (aggregation-AMG PCG) even on lattice meshes; "ell-jacobi": general path
+        # with the plain Jacobi preconditioner
+        self.method = method
+        # aggregation AMG of the general path: V-cycle (gamma = 1) with the coarse correction scaled by 1.8
+        # (over-correction compensates the piecewise-constant interpolation; < 2 keeps the cycle a contraction)
+        self.amg = dict(n_coarse=16, gamma=1, scale=1.8)
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)

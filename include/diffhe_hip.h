@@ -143,6 +143,32 @@ int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, do
                         int Bv, double tol, int max_iter, int check_every, double* work, double* relres,
                         int* iters, int* status_host, void* stream);
 
+/* ------------------------------------------------------------------------------
+ * Aggregation multigrid for general meshes.  The hierarchy (aggregates, coarse ELL patterns,
+ * Galerkin gather lists) is batch-shared and built on the host once per mesh; coarse VALUES are
+ * P^T A P with piecewise-constant P = sums of fine entries, rebuilt per solve / per sample.
+ * ---------------------------------------------------------------------------- */
+typedef struct diffhe_amg_level {
+  int n, W;                /* nodes and ELL width of this level */
+  const double* vals;      /* (W, n, Bv) */
+  const int* cols;         /* (W, n) */
+  const int* agg;          /* (n) node -> node of the NEXT level, -1 = none (Dirichlet); NULL on the last level */
+  const int* agg_ptr;      /* (n_next + 1) CSR of the members of each next-level node; NULL on the last level */
+  const int* agg_members;  /* node ids, grouped by aggregate */
+} diffhe_amg_level;
+
+/* vals_coarse[(k*n_coarse + I)*Bv + b] = sum of vals_fine[contrib[c]*Bv + b], c in ent_ptr[k*n_coarse+I] .. */
+int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, double* vals_coarse,
+                        int n_coarse, int W_coarse, int Bv, void* stream);
+/* Batched CG preconditioned by one aggregation-multigrid cycle: V(2,2) Chebyshev-weighted Jacobi,
+ * `gamma` coarse corrections per level (2 = W-cycle), coarse correction scaled by `scale`, n_coarse
+ * sweeps on the last level.  Replaces torch.linalg.solve (solver.py:174) on general meshes.
+ * Arguments as diffhe_ell_cg_solve; levels is a HOST array. */
+long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* levels, int n_levels, int Bp);
+int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x, int Bp,
+                             double tol, int max_iter, int n_coarse, int gamma, double scale, double* work,
+                             double* relres, int* iters, int* status_host, void* stream);
+
 /* One application of the batched operator, y = A x, with the per-sample dots x.y left as
  * block partials in `part` (diffhe_grad_kappa_blocks(n, Bp) * Bp doubles): the very kernel
  * the CG loop launches once per iteration, exposed so it can be timed and tested alone. */

@@ -256,3 +256,48 @@ def test_coarsening_step_rules():
     assert coarsening_step(grid(6, 6, 1.0, 1.0)) == (2, 2)
     assert coarsening_step(grid(3, 3, 1.0, 1.0)) is None          # odd: stop
     assert coarsening_step(grid(64, 5, 8.0, 1.0)) is None         # would need the rows, which do not halve
+
+
+def test_aggregation_hierarchy_galerkin_lists():
+    """diffhe/amg.py: aggregates cover every free node once, roots are >= 3 apart, and the gather lists
+    reproduce P^T A P for piecewise-constant P (numpy model of diffhe_ell_galerkin)."""
+    from diffhe.amg import build_hierarchy
+    m = FEMesh.rectangle(14, 11, (0.0, 2.0), (0.0, 1.0))
+    nodes, elements, bc_nodes, _ = _arrays(m)
+    n = m.n_nodes
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(n)
+    el = perm[elements]
+    nd = nodes[np.argsort(perm)]
+    is_bc = np.zeros(n, dtype=np.uint8)
+    is_bc[perm[bc_nodes]] = 1
+    pat = build_ell_pattern(el, n)
+    K, _ = orc.assemble_dense(nd, el, rng.uniform(0.5, 2.0, len(el)), np.zeros(n))
+    free = is_bc == 0
+    K[~free, :] = 0.0
+    K[:, ~free] = 0.0
+    K[~free, ~free] = 1.0
+    W, cols = pat["W"], pat["cols"]
+    vals = np.stack([K[np.arange(n), cols[k]] * ((k == 0) | (cols[k] != np.arange(n))) for k in range(W)])
+    levels = build_hierarchy(cols, is_bc, min_coarse=6)
+    assert len(levels) >= 2
+    A, v = K, vals
+    for lv in levels:
+        agg, nc = lv["agg"], lv["n"]
+        act = agg >= 0
+        assert np.array_equal(np.unique(agg[act]), np.arange(nc))
+        P = np.zeros((A.shape[0], nc))
+        P[np.nonzero(act)[0], agg[act]] = 1.0
+        Ac = P.T @ A @ P
+        ptr, contrib = lv["ent_ptr"], lv["contrib"]
+        ent_of = np.repeat(np.arange(lv["W"] * nc), np.diff(ptr))
+        vc = np.bincount(ent_of, weights=v.ravel()[contrib], minlength=lv["W"] * nc).reshape(lv["W"], nc)
+        Ac2 = np.zeros((nc, nc))
+        used = np.diff(ptr).reshape(lv["W"], nc) > 0
+        for k in range(lv["W"]):
+            Ac2[np.arange(nc)[used[k]], lv["cols"][k][used[k]]] += vc[k][used[k]]
+        assert np.max(np.abs(Ac - Ac2)) < 1e-12 * np.max(np.abs(Ac))
+        assert np.array_equal(lv["cols"][0], np.arange(nc))
+        members = lv["agg_members"]
+        assert np.array_equal(np.sort(members), np.nonzero(act)[0])
+        A, v = Ac, vc
