@@ -325,6 +325,12 @@ def _solve_forward(solver, kappa, f):
     the explicit adjoint needs (assembled operators, the eliminated solution, layout facts)."""
     ctx = types.SimpleNamespace()
     plan: SolvePlan = solver._plan()
+    if solver._tol_user is None:
+        # fully Dirichlet-bounded lattices are well conditioned relative to their size (error ~ residual under
+        # multigrid); partly Neumann boundaries and the general path get one more decade
+        lattice = plan.is_lattice and solver.method == "auto"
+        closed = lattice and plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
+        solver.tol = 1e-12 if closed or plan.is_chain else (1e-14 if lattice else 1e-13)
     eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
     out_device = f.device
     batched = f.dim() == 2
@@ -551,7 +557,7 @@ class DifferentiableFESolver(nn.Module):
         the multigrid parameters (nu, n_coarse, omega) of the lattice path.
     """
 
-    def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: float = 1e-12,
+    def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
                  mg: Optional[dict] = None):
         super().__init__()
@@ -584,6 +590,8 @@ class DifferentiableFESolver(nn.Module):
         self._device = device
         if os.environ.get("DIFFHE_TOL"):
             tol = float(os.environ["DIFFHE_TOL"])
+        # relative-residual stop; None = chosen per mesh at the first solve (1e-12 or 1e-13, see _solve_forward)
+        self._tol_user = tol
         self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
         self.last_info = SolveInfo()
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the CPU oracle (development aid; needs a GPU).
+Varies mesh kind/size, Dirichlet sets, kappa layout, batch size and checks u, dL/dkappa, dL/df."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "difffe-physics-lab_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from diffhe import FEMesh, DifferentiableFESolver  # noqa: E402
+from oracle import p1_oracle as orc  # noqa: E402
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+worst = 0.0
+for case in range(n_cases):
+    kind = rng.choice(["line", "rect", "rect_bc", "unstructured"])
+    if kind == "line":
+        N = int(rng.integers(2, 400))
+        bl, br = rng.choice([None, 0.0, 1.3]), rng.choice([0.0, -0.7])
+        mesh = FEMesh.line(N, -1.0, 2.0, bl, br)
+    else:
+        nx, ny = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        mesh = FEMesh.rectangle(nx, ny, (0.0, float(rng.uniform(0.5, 6.0))), (0.0, 1.0), float(rng.uniform(-1, 1)))
+        if kind == "rect_bc":      # Dirichlet only on part of the boundary (+ one interior node): Neumann elsewhere
+            keys = list(mesh.dirichlet_nodes)
+            keep = [k for k in keys if mesh.nodes[k, 0] == 0.0] + [int(rng.integers(0, mesh.n_nodes))]
+            mesh.dirichlet_nodes = {k: float(rng.uniform(-1, 1)) for k in keep}
+        if kind == "unstructured":
+            perm = rng.permutation(mesh.n_nodes)
+            nodes = np.empty_like(mesh.nodes.numpy())
+            nodes[perm] = mesh.nodes.numpy()
+            el = perm[mesh.elements.numpy()][rng.permutation(mesh.n_elements)]
+            mesh = FEMesh(torch.from_numpy(nodes), torch.from_numpy(el),
+                          {int(perm[k]): v for k, v in mesh.dirichlet_nodes.items()})
+    n, m = mesh.n_nodes, mesh.n_elements
+    B = int(rng.choice([1, 2, 3, 17, 64, 70]))
+    kmode = rng.choice(["scalar", "sample", "elem", "sample_elem"])
+    kap = {"scalar": np.array(rng.uniform(0.5, 2.0)), "sample": rng.uniform(0.5, 2.0, B),
+           "elem": np.exp(0.4 * rng.standard_normal(m)), "sample_elem": np.exp(0.4 * rng.standard_normal((B, m)))}[kmode]
+    if kmode in ("sample", "sample_elem") and B == m:
+        B += 1
+    f = 1 + 0.5 * rng.standard_normal((B, n))
+    kt = torch.from_numpy(np.atleast_1d(kap) if kmode != "scalar" else kap).requires_grad_(True)
+    ft = torch.from_numpy(f).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(ft)
+    (u ** 2).sum().backward()
+    bn = np.array(list(mesh.dirichlet_nodes.keys()), dtype=np.int64)
+    bv = np.array(list(mesh.dirichlet_nodes.values()))
+    errs = []
+    dk_ref = np.zeros_like(np.atleast_1d(kap), dtype=np.float64) if kmode != "scalar" else 0.0
+    for b in range(B):
+        kb = kap if kmode in ("scalar", "elem") else kap[b]
+        uo, dko, dfo = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[b], lambda u: 2 * u)
+        sc = max(np.max(np.abs(uo)), 1e-300)
+        errs.append(np.max(np.abs(u[b].detach().numpy() - uo)) / sc)
+        errs.append(np.max(np.abs(ft.grad[b].numpy() - dfo)) / max(np.max(np.abs(dfo)), 1e-300))
+        if kmode == "scalar":
+            dk_ref += dko.sum()
+        elif kmode == "sample":
+            dk_ref[b] = dko.sum()
+        elif kmode == "elem":
+            dk_ref += dko
+        else:
+            dk_ref[b] = dko
+    errs.append(np.max(np.abs(kt.grad.numpy() - dk_ref)) / max(np.max(np.abs(dk_ref)), 1e-300))
+    e = max(errs)
+    worst = max(worst, e)
+    flag = "" if e < 1e-10 else "   <-- ABOVE 1e-10"
+    print(f"case {case:3d} {kind:12s} n={n:5d} B={B:3d} kappa={kmode:11s} path={solver.last_info.path:14s} "
+          f"iters={solver.last_info.iterations:4d} err={e:.1e}{flag}", flush=True)
+print("worst", worst)
