@@ -325,12 +325,6 @@ def _solve_forward(solver, kappa, f):
     the explicit adjoint needs (assembled operators, the eliminated solution, layout facts)."""
     ctx = types.SimpleNamespace()
     plan: SolvePlan = solver._plan()
-    if solver._tol_user is None:
-        # fully Dirichlet-bounded lattices are well conditioned relative to their size (error ~ residual under
-        # multigrid); partly Neumann boundaries and the general path get one more decade
-        lattice = plan.is_lattice and solver.method == "auto"
-        closed = lattice and plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
-        solver.tol = 1e-12 if closed or plan.is_chain else (1e-14 if lattice else 1e-13)
     eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
     out_device = f.device
     batched = f.dim() == 2
@@ -340,6 +334,16 @@ def _solve_forward(solver, kappa, f):
     B = B_f if B_f is not None else (B_k if B_k is not None else 1)
     if B_k is not None and B_k != B:
         raise ValueError(f"kappa batch {B_k} does not match f batch {B}")
+    if solver._tol_user is None:
+        # Default stop (relative residual).  Fully Dirichlet-bounded lattices with one kappa per sample are well
+        # conditioned for their size and multigrid keeps error ~ residual: 1e-12 (validated against the oracle
+        # in every bench run).  Per-element fields (their per-element gradients amplify solver error), partly
+        # Neumann boundaries and the general path get one or two more decades.
+        lattice = plan.is_lattice and solver.method == "auto"
+        closed = lattice and plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
+        simple = mode in (K_SCALAR, K_SAMPLE)
+        solver.tol = 1e-12 if (plan.is_chain or (closed and simple)) else (1e-13 if closed or not lattice else 1e-14)
+        eng.tol = solver.tol
     f_dev = f.detach().to(plan.device, torch.float64).contiguous()
     info = SolveInfo()
     ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
