@@ -14,15 +14,17 @@ from oracle import p1_oracle as orc  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"      # strip-kernel sizes, wave-sized batches, 3 samples checked
 worst = 0.0
 for case in range(n_cases):
     kind = rng.choice(["line", "rect", "rect_bc", "unstructured"])
     if kind == "line":
-        N = int(rng.integers(2, 400))
+        N = int(rng.integers(2, 400)) if not LARGE else int(rng.integers(2000, 12000))
         bl, br = rng.choice([None, 0.0, 1.3]), rng.choice([0.0, -0.7])
         mesh = FEMesh.line(N, -1.0, 2.0, bl, br)
     else:
-        nx, ny = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        nx, ny = (int(rng.integers(2, 70)), int(rng.integers(2, 70))) if not LARGE else \
+            (int(rng.integers(190, 420)), int(rng.integers(64, 300)))
         mesh = FEMesh.rectangle(nx, ny, (0.0, float(rng.uniform(0.5, 6.0))), (0.0, 1.0), float(rng.uniform(-1, 1)))
         if kind == "rect_bc":      # Dirichlet only on part of the boundary (+ one interior node): Neumann elsewhere
             keys = list(mesh.dirichlet_nodes)
@@ -36,7 +38,7 @@ for case in range(n_cases):
             mesh = FEMesh(torch.from_numpy(nodes), torch.from_numpy(el),
                           {int(perm[k]): v for k, v in mesh.dirichlet_nodes.items()})
     n, m = mesh.n_nodes, mesh.n_elements
-    B = int(rng.choice([1, 2, 3, 17, 64, 70]))
+    B = int(rng.choice([1, 2, 3, 17, 64, 70])) if not LARGE else int(rng.choice([64, 100, 128, 192]))
     kmode = rng.choice(["scalar", "sample", "elem", "sample_elem"])
     kap = {"scalar": np.array(rng.uniform(0.5, 2.0)), "sample": rng.uniform(0.5, 2.0, B),
            "elem": np.exp(0.4 * rng.standard_normal(m)), "sample_elem": np.exp(0.4 * rng.standard_normal((B, m)))}[kmode]
@@ -52,9 +54,18 @@ for case in range(n_cases):
     bv = np.array(list(mesh.dirichlet_nodes.values()))
     errs = []
     dk_ref = np.zeros_like(np.atleast_1d(kap), dtype=np.float64) if kmode != "scalar" else 0.0
-    for b in range(B):
+    check = range(B) if not LARGE else sorted({0, B // 2, B - 1})
+    if LARGE and kmode in ("scalar", "elem"):
+        kmode_grad_partial = True       # gradient of a shared kappa sums over ALL samples: only compare u and df
+    else:
+        kmode_grad_partial = False
+    for b in check:
         kb = kap if kmode in ("scalar", "elem") else kap[b]
-        uo, dko, dfo = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[b], lambda u: 2 * u)
+        if kind == "line" and n > 1500:   # fp64 LU is itself ~cond*eps off there: use the extended-precision oracle
+            uo, dko, dfo = orc.chain_solve_longdouble(mesh.nodes.numpy(), bn, bv, kb, f[b], lambda u: 2 * u)
+        else:
+            uo, dko, dfo = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[b],
+                                                  lambda u: 2 * u)
         sc = max(np.max(np.abs(uo)), 1e-300)
         errs.append(np.max(np.abs(u[b].detach().numpy() - uo)) / sc)
         errs.append(np.max(np.abs(ft.grad[b].numpy() - dfo)) / max(np.max(np.abs(dfo)), 1e-300))
@@ -66,7 +77,11 @@ for case in range(n_cases):
             dk_ref += dko
         else:
             dk_ref[b] = dko
-    errs.append(np.max(np.abs(kt.grad.numpy() - dk_ref)) / max(np.max(np.abs(dk_ref)), 1e-300))
+    if not kmode_grad_partial:
+        got = kt.grad.numpy()
+        if LARGE:
+            got, dk_ref = got[list(check)], dk_ref[list(check)]
+        errs.append(np.max(np.abs(got - dk_ref)) / max(np.max(np.abs(dk_ref)), 1e-300))
     e = max(errs)
     worst = max(worst, e)
     flag = "" if e < 1e-10 else "   <-- ABOVE 1e-10"
