@@ -28,6 +28,14 @@ struct Level {
   const unsigned char* bc;  // (n)
 };
 
+// 1/d for the smoother: hardware v_rcp_f64 (~2^-23 relative) + one Newton step (~1e-14) -- 4 instructions
+// instead of the ~30 of an IEEE fp64 division.  D^-1 only has to be the same positive diagonal everywhere in
+// the preconditioner, so the remaining 1e-14 is immaterial.
+__device__ inline double fast_rcp(double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  return fma(r0, fma(-d, r0, 1.0), r0);
+}
+
 __device__ inline int dia_off(const Level& L, int k) { return k == 1 ? 1 : (k == 2 ? L.W : L.nx); }
 
 // sum_j K[i,j] x[j] for sample b (unscaled)
@@ -106,13 +114,13 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double sc = row_scale(L, scale, i, nm.b);
-    const double d = sc * L.v[(i64)i * Bv + vb];
+    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb]);  // same reciprocal as the strip kernels
     const double bi = (double)bvec[o];
     double xo;
     if (xin)
-      xo = (double)xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) / d;
+      xo = (double)xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) * dinv;
     else
-      xo = omega * bi / d;
+      xo = omega * bi * dinv;
     xout[o] = (TV)xo;
     s += bi * xo;
   }
@@ -197,6 +205,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   TV* __restrict__ po = out ? out + i0 * Bp : nullptr;
   const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
 
+  const double inv_omega_in = XFROMB ? 1.0 / omega_in : 0.0;
   const double beta = (FUSE == F_PUPD && !ex.first) ? ex.beta[b] : 0.0;
   const double alpha_prev = (FUSE == F_PUPD && !ex.first) ? ex.alpha[b] : 0.0;
   const TA* __restrict__ aux = (const TA*)ex.a0;
@@ -234,7 +243,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       } else {
         v = (double)(xrow + (i64)dq[q] * Bp)[lb];
       }
-      if (XFROMB) v = omega_in * v / (sb * (double)(d0row + (i64)dq[q] * Bv)[lv]);
+      if (XFROMB) v = omega_in * v * fast_rcp(sb * (double)(d0row + (i64)dq[q] * Bv)[lv]);
       if (FUSE == F_PROLONG) {
         double corr;  // c0w is even: window column q has the parity of q + 1
         if (q & 1)
@@ -303,13 +312,15 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           if (!ex.first) (pxx + o)[lb] += alpha_prev * (double)(ppi + o)[lb];
         }
       } else {
-        const double bi = XFROMB ? xc[q] * (sb * d0[k]) / omega_in : (double)(pb + o)[lb];
+        const double dinv = (MODE == M_JACOBI) ? fast_rcp(sb * d0[k]) : 0.0;
+        // XFROMB: the window holds x1 = omega_in * rhs * dinv, so rhs = x1 / (omega_in * dinv)
+        const double bi = XFROMB ? xc[q] * (sb * d0[k]) * inv_omega_in : (double)(pb + o)[lb];
         const double res = bi - sb * acc;
         if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
           s += res * res;
         } else {
-          const double xo = xc[q] + omega * res / (sb * d0[k]);
+          const double xo = xc[q] + omega * res * dinv;
           (po + o)[lb] = (TV)xo;
           s += bi * xo;
         }
@@ -426,11 +437,11 @@ __global__ __launch_bounds__(256) void dia_cheby_kernel(Level L, int Bv, const d
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double sc = row_scale(L, scale, i, nm.b);
-    const double d = sc * L.v[(i64)i * Bv + vb];
+    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb]);
     const double bi = (double)bvec[o];
     const double xi = xin ? (double)xin[o] : 0.0;
     const double res = xin ? bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp) : bi;
-    const double dn = (din ? c1 * (double)din[o] : 0.0) + c2 * res / d;
+    const double dn = (din ? c1 * (double)din[o] : 0.0) + c2 * res * dinv;
     dout[o] = (TV)dn;
     const double xo = xi + dn;
     xout[o] = (TV)xo;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table from a rocprofv3 kernel trace of `bench.py` (default workload).
+
+    python tools/roofline_table.py gpurun_out/prof_dir/*/..._kernel_trace.csv > profiles/rNN_roofline_table.md
+
+For every strip/vector kernel instance launched on the FINE level (identified by its grid size) the
+algorithmic bytes per launch (8 n Bp = one fp64 vector pass) are divided by the
+average duration.  Coarse-level launches are summed separately."""
+import collections
+import csv
+import sys
+
+N, BP = 1025 * 1025, 256
+PASS = 8.0 * N * BP
+# (substring of the kernel name, template-argument pattern) -> (label, algorithmic passes per launch)
+RULES = [
+    ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step (p, x update + A p + dot), z/p fp32", 4.5),
+    ("dia_strip_kernel<double, double, double, 0, 2", "fused CG step, z/p fp64", 6.0),
+    ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
+    ("dia_strip_kernel<float, float, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp32)", 1.0),
+    ("dia_strip_kernel<float, float, double, 1, 0", "residual (fp32)", 1.5),
+    ("mg_restrict_strip_kernel<float", "restriction (fp32)", 0.625),
+    ("dia_strip_kernel<float, float, double, 2, 1", "prolong + correct + Jacobi sweep (fp32)", 1.625),
+    ("dia_strip_kernel<float, float, double, 2, 0, 3, true, false", "Jacobi sweep (fp32)", 1.5),
+    ("dia_strip_kernel<double, double, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp64)", 2.0),
+    ("dia_strip_kernel<double, double, double, 1, 0", "residual (fp64)", 3.0),
+    ("mg_restrict_strip_kernel<double", "restriction (fp64)", 1.25),
+    ("dia_strip_kernel<double, double, double, 2, 1", "prolong + correct + Jacobi sweep (fp64)", 3.25),
+    ("dia_strip_kernel<double, double, double, 2, 0, 3, true, false", "Jacobi sweep (fp64)", 3.0),
+    ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),
+    ("pcg_init_kernel", "x = 0, r = b, b.b", 3.5),
+    ("to_node_major_kernel", "(B,n) -> (n,Bp)", 2.0),
+    ("to_sample_major_kernel", "(n,Bp) -> (B,n)", 2.0),
+    ("dia_shared_apply_kernel", "F = M f - lift", 2.0),
+]
+
+
+def main(path):
+    per = collections.defaultdict(list)
+    total = 0
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            total += d
+            per[name.split("(")[0]].append(d)
+    print("| kernel | launches (fine level) | avg ms | algorithmic GB/s | frac of 8 TB/s | share of GPU time |")
+    print("|---|---|---|---|---|---|")
+    seen = 0
+    for key, label, passes in RULES:
+        for name, durs in per.items():
+            if key in name:
+                top = max(durs)
+                fine = [d for d in durs if d > 0.6 * top]        # fine-level launches dominate the duration
+                avg = sum(fine) / len(fine)
+                gbs = passes * PASS / (avg * 1e-9) / 1e9
+                share = sum(durs) / total
+                seen += sum(durs)
+                print(f"| `{label}` | {len(fine)} | {avg / 1e6:.3f} | {gbs:.0f} | {gbs / 8000:.2f} | {100 * share:.1f} % (all levels) |")
+    print(f"| everything else (coarse-level simple kernels, scalars, torch ops) | | | | | {100 * (total - seen) / total:.1f} % |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
