@@ -913,7 +913,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
       if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
-        constexpr int CW = 4;
+        constexpr int CW = 8;
         const int ncb = (C.W + 4 * CW - 1) / (4 * CW);
         int nrc = (4096 + ncb * (H.Bp / kWave) - 1) / (ncb * (H.Bp / kWave));
         if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
