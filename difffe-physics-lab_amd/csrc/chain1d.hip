@@ -8,12 +8,16 @@
 //     u_{j}   = u_a + C R_j - T_j,    R_j = sum_{e<j} 1/k_e,  T_j = sum_{e<j} S_e / k_e
 // and C, u_a follow from the two segment ends.  (F,R,T) compose associatively:
 //     (F1,R1,T1) o (F2,R2,T2) = (F1+F2, R1+R2, T1+T2+F1*R2)
-// so the solve is ONE block scan per (segment, sample) plus two thread-local sweeps over
-// an LDS-staged copy of the segment.  HBM traffic: read f, write u (16 n B); the adjoint
+// so the solve is ONE scan per (segment, sample).  HBM traffic: read f, write u (16 n B); the adjoint
 // reads gbar and u and writes df (+ dkappa): 24-32 n B.  K is never materialised.
 //
-// One workgroup per (segment, sample).  Thread t owns the odd-length chunk
-// [t*c, (t+1)*c) of the staged arrays: odd c makes the stride-c LDS reads conflict-free.
+// One workgroup per (segment, sample), two kernels:
+//   chain_reg_kernel  segments up to 10 240 elements: the segment lives in REGISTERS, element order =
+//                     thread order, so every global access is coalesced; scan = DPP row shifts across the
+//                     wave + one LDS pass over the wave totals.
+//   chain_kernel      longer segments: element integrals staged in a global scratch buffer (L2-resident
+//                     while the workgroup uses it); thread t owns the chunk [t*c, (t+1)*c) of the staged
+//                     arrays, block scan over the chunk composites.
 #include "common.h"
 
 namespace {
@@ -49,7 +53,7 @@ struct ChainArgs {
   long long lddk;
   double* dk_part;       // adjoint only
   int n, B;
-  double* stage;         // global staging (only when !USE_LDS)
+  double* stage;         // global staging (chain_kernel only)
   long long stage_len;   // doubles per (sample, segment) half-buffer
 };
 
@@ -60,9 +64,8 @@ __device__ inline double lumped_weight(const double* x, int i, int n) {
   return 0.5 * (hl + hr);
 }
 
-template <int NT, bool ADJ, bool USE_LDS>
+template <int NT, bool ADJ>
 __global__ __launch_bounds__(NT) void chain_kernel(ChainArgs A) {
-  extern __shared__ double dyn[];
   __shared__ Trip wtot[NT / 64];
   __shared__ double red[NT / 64];
   __shared__ double bc_vals[3];  // u_a, C, load at the right end
@@ -76,15 +79,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainArgs A) {
   if (L <= 0) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-  double* Fs;
-  double* Rs;
-  if (USE_LDS) {
-    Fs = dyn;
-    Rs = dyn + L;
-  } else {
-    Fs = A.stage + ((long long)b * A.n_seg + s) * 2 * A.stage_len;
-    Rs = Fs + A.stage_len;
-  }
+  double* Fs = A.stage + ((long long)b * A.n_seg + s) * 2 * A.stage_len;
+  double* Rs = Fs + A.stage_len;
   const double* rhs = A.rhs + (long long)b * A.rhs_sb;
   const double* kap = A.kappa + (long long)b * A.ksb;
 
@@ -194,30 +190,209 @@ __global__ __launch_bounds__(NT) void chain_kernel(ChainArgs A) {
   }
 }
 
-constexpr int kLdsBudget = 160 * 1024 - 2048;  // dynamic bytes one workgroup may take
 
-template <int NT, bool ADJ>
-int launch_nt(const ChainArgs& A, int max_len, hipStream_t st) {
-  dim3 grid(A.n_seg, A.B);
-  const size_t need = (size_t)2 * max_len * sizeof(double);
-  if (need <= (size_t)kLdsBudget) {
-    auto k = chain_kernel<NT, ADJ, true>;
-    if (need > 48 * 1024) {
-      int rc = check(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      if (rc) return rc;
+// ---- register-resident variant (segments up to NT * EPT elements) -----------------------------
+// Element q = k*NT + t lives in the registers of thread t (round k), so every global access is
+// coalesced and nothing is staged: each round is scanned across the wave with DPP row shifts /
+// row broadcasts of the (F,R,T) triple, the EPT * NT/64 wave totals are scanned once by wave 0
+// through LDS, and each thread finishes its own elements from (block prefix) o (in-wave prefix).
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_f64(double v) {  // lanes without a source lane (or in masked rows) read 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline Trip scan_step(const Trip& v) {
+  const Trip o = {dpp_f64<CTRL, ROW_MASK>(v.F), dpp_f64<CTRL, ROW_MASK>(v.R), dpp_f64<CTRL, ROW_MASK>(v.T)};
+  return comb(o, v);  // (0,0,0) is the identity, so lanes that received nothing are unchanged
+}
+
+__device__ inline Trip wave_scan(Trip v) {  // inclusive scan over the 64 lanes, lane order = element order
+  v = scan_step<0x111, 0xf>(v);  // row_shr:1
+  v = scan_step<0x112, 0xf>(v);  // row_shr:2
+  v = scan_step<0x114, 0xf>(v);  // row_shr:4
+  v = scan_step<0x118, 0xf>(v);  // row_shr:8
+  v = scan_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = scan_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// 1/d to within an ulp or so: hardware reciprocal + two Newton steps (a tenth of the IEEE division's cost)
+__device__ inline double rcp_newton(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return fma(r, fma(-d, r, 1.0), r);
+}
+
+// One element's scan inputs: F (load, 0 at a left Dirichlet end), r = 1/k_e and h_e.
+template <bool ADJ>
+__device__ inline void chain_elem(const ChainArgs& A, const double* rhs, const double* kap, int a, int q, bool left_d,
+                                  double& F, double& r, double& he) {
+  const int e = a + q;
+  const double xe = A.x[e];
+  he = A.x[e + 1] - xe;                                                        // solver.py:84-86
+  const double w = ADJ ? 1.0 : 0.5 * ((e > 0 ? xe - A.x[e - 1] : 0.0) + he);   // solver.py:95-96
+  F = (q == 0 && left_d) ? 0.0 : rhs[e] * w;
+  r = he * rcp_newton(kap[(long long)e * A.kse]);                              // 1 / k_e, solver.py:88
+}
+
+// Thread t owns the VEC consecutive elements (k*NT + t)*VEC .. +VEC-1 of round k (EPT = rounds * VEC
+// elements per thread).  KEEP = 2: the element inputs (F, r) stay in registers between the two phases;
+// 1: only F, r is recomputed; 0: both are loaded again for the output phase.  Measured on config 2
+// (10^4 elements x 4096 samples): KEEP = 2 with VEC = 2 is fastest -- larger VEC (fewer scan rounds but
+// strided loads) and the smaller-register variants that fit two workgroups per CU were all slower.
+template <int NT, int EPT, int VEC, bool ADJ, int KEEP>
+__global__ __launch_bounds__(NT) void chain_reg_kernel(ChainArgs A) {
+  constexpr int NW = NT / 64;
+  constexpr int RND = EPT / VEC;
+  constexpr int NB = RND * NW;          // wave-sized blocks of the segment, in element order
+  constexpr int PER = (NB + 63) / 64;   // blocks per lane in the second-level scan
+  static_assert(EPT % VEC == 0, "EPT must be a multiple of VEC");
+  __shared__ Trip blk[NB + 1];          // block composites, then their exclusive prefixes; [NB] = total
+  __shared__ double red[NW];
+
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int a = A.seg[3 * s + 0];
+  const int bn = A.seg[3 * s + 1];
+  const int flags = A.seg[3 * s + 2];
+  const bool left_d = flags & 1, right_d = flags & 2;
+  const int L = bn - a;
+  if (L <= 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* rhs = A.rhs + (long long)b * A.rhs_sb;
+  const double* kap = A.kappa + (long long)b * A.ksb;
+
+  Trip excl[RND];                       // in-wave exclusive prefix of this thread's run, per round
+  double Fk[KEEP >= 1 ? EPT : 1], rk[KEEP >= 2 ? EPT : 1];
+#pragma unroll
+  for (int k = 0; k < RND; ++k) {
+    Trip run = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int q = (k * NT + t) * VEC + j;
+      double F = 0.0, r = 0.0, he;
+      if (q < L) chain_elem<ADJ>(A, rhs, kap, a, q, left_d, F, r, he);
+      if (KEEP >= 1) Fk[k * VEC + j] = F;
+      if (KEEP >= 2) rk[k * VEC + j] = r;
+      run.F += F;
+      run.R += r;
+      run.T += run.F * r;
     }
-    hipLaunchKernelGGL(k, grid, dim3(NT), need, st, A);
-  } else {
-    if (!A.stage) return DIFFHE_E_TOOBIG;
-    hipLaunchKernelGGL((chain_kernel<NT, ADJ, false>), grid, dim3(NT), 0, st, A);
+    const Trip incl = wave_scan(run);
+    excl[k] = {dpp_f64<0x138, 0xf>(incl.F), dpp_f64<0x138, 0xf>(incl.R), dpp_f64<0x138, 0xf>(incl.T)};  // wave_shr:1
+    if (lane == 63) blk[k * NW + wave] = incl;
   }
+  __syncthreads();
+  if (wave == 0) {
+    Trip loc[PER];
+    Trip acc = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int idx = lane * PER + j;
+      loc[j] = acc;
+      if (idx < NB) acc = comb(acc, blk[idx]);
+    }
+    const Trip incl = wave_scan(acc);
+    const Trip ex = {dpp_f64<0x138, 0xf>(incl.F), dpp_f64<0x138, 0xf>(incl.R), dpp_f64<0x138, 0xf>(incl.T)};
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int idx = lane * PER + j;
+      if (idx < NB) blk[idx] = comb(ex, loc[j]);
+    }
+    if (lane == 63) blk[NB] = incl;
+  }
+  __syncthreads();
+  const Trip total = blk[NB];
+
+  // ---- segment constants (solver.py:165-181 by cases) --------------------------------
+  const double ga = (A.g && left_d) ? A.g[a] : 0.0;
+  const double gb = (A.g && right_d) ? A.g[bn] : 0.0;
+  double ua, C;
+  if (left_d && right_d) {
+    ua = ga;
+    C = (gb - ga + total.T) / total.R;
+  } else if (left_d) {
+    ua = ga;
+    C = total.F + rhs[bn] * (ADJ ? 1.0 : lumped_weight(A.x, bn, A.n));
+  } else if (right_d) {
+    C = 0.0;
+    ua = gb + total.T;
+  } else {  // pure Neumann: singular (the reference returns garbage, solver.py:174)
+    ua = C = __builtin_nan("");
+  }
+
+  double* out = A.out + (long long)b * A.ldo;
+  const double* u = ADJ ? A.u + (long long)b * A.ldu : nullptr;
+  double part = 0.0;
+#pragma unroll
+  for (int k = 0; k < RND; ++k) {
+    Trip p = comb(blk[k * NW + wave], excl[k]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int q = (k * NT + t) * VEC + j;
+      if (q < L) {
+        double F, r, he;
+        if (KEEP >= 2) {
+          F = Fk[k * VEC + j];
+          r = rk[k * VEC + j];
+          if (ADJ) he = A.x[a + q + 1] - A.x[a + q];
+        } else if (KEEP == 1) {
+          F = Fk[k * VEC + j];
+          he = A.x[a + q + 1] - A.x[a + q];
+          r = he * rcp_newton(kap[(long long)(a + q) * A.kse]);
+        } else {
+          chain_elem<ADJ>(A, rhs, kap, a, q, left_d, F, r, he);
+        }
+        p.F += F;
+        p.R += r;
+        p.T += p.F * r;
+        const double val = ua + C * p.R - p.T;        // value at node a+q+1
+        const bool last_d = (q == L - 1) && right_d;
+        if (!ADJ) {
+          out[a + q + 1] = last_d ? gb : val;
+        } else {
+          const int e = a + q;
+          out[e + 1] = last_d ? 0.0 : val * lumped_weight(A.x, e + 1, A.n);  // df = M^T lambda
+          const double dlam = (C - p.F) * r;                                  // lambda_{e+1} - lambda_e
+          const double dk = -dlam * (u[e + 1] - u[e]) / he;                   // -lam_e^T k0_e u_e
+          if (A.dk_e) A.dk_e[(long long)b * A.lddk + e] = dk;
+          part += dk;
+        }
+      }
+    }
+  }
+  if (t == 0) out[a] = ADJ ? (left_d ? 0.0 : ua * lumped_weight(A.x, a, A.n)) : ua;
+  if (ADJ) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    if (t == 0) {
+      double sum = 0.0;
+      for (int w = 0; w < NW; ++w) sum += red[w];
+      A.dk_part[(long long)b * A.n_seg + s] = sum;
+    }
+  }
+}
+
+template <int NT, int EPT, int VEC, bool ADJ, int KEEP>
+int launch_reg(const ChainArgs& A, hipStream_t st) {
+  hipLaunchKernelGGL((chain_reg_kernel<NT, EPT, VEC, ADJ, KEEP>), dim3(A.n_seg, A.B), dim3(NT), 0, st, A);
   return check_launch();
 }
 
 template <bool ADJ>
 int launch(const ChainArgs& A, int max_len, hipStream_t st) {
-  if (max_len <= 2048) return launch_nt<256, ADJ>(A, max_len, st);
-  return launch_nt<1024, ADJ>(A, max_len, st);
+  if (max_len <= 256) return launch_reg<64, 4, 2, ADJ, 2>(A, st);
+  if (max_len <= 1024) return launch_reg<256, 4, 2, ADJ, 2>(A, st);
+  if (max_len <= 4096) return launch_reg<1024, 4, 2, ADJ, 2>(A, st);
+  if (max_len <= 10240) return launch_reg<1024, 10, 2, ADJ, 2>(A, st);
+  if (!A.stage) return DIFFHE_E_TOOBIG;
+  hipLaunchKernelGGL((chain_kernel<1024, ADJ>), dim3(A.n_seg, A.B), dim3(1024), 0, st, A);
+  return check_launch();
 }
 
 // Longest segment: the host passes n; segments never exceed n - 1 elements.  We size

@@ -972,7 +972,8 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
   }
   {  // coarsest level: the V-cycle from `last` is n_coarse Jacobi sweeps
     TV* e = vcycle<TV>(H, bl[last], nullptr, nullptr, st, last);
-    hipMemcpyAsync(H.xF[last], e, (size_t)H.lev[last].n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st);
+    if (diffhe::check(hipMemcpyAsync(H.xF[last], e, (size_t)H.lev[last].n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st)))
+      return nullptr;  // error text recorded for diffhe_last_hip_error()
   }
   for (int l = last - 1; l >= 0; --l) {
     const Level& L = H.lev[l];
@@ -1120,9 +1121,11 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   if (use_fmg) {  // x0 = FMG(b); r = b - A x0
     if (f32) {
       const float* x0 = fmg_start<float>(H, (const float*)r32, st);
+      if (!x0) return DIFFHE_E_LAUNCH;
       LAUNCH(pcg_setx_kernel<float>, n, x0, x, n, Bp);
     } else {
       const double* x0 = fmg_start<double>(H, b, st);
+      if (!x0) return DIFFHE_E_LAUNCH;
       LAUNCH(pcg_setx_kernel<double>, n, x0, x, n, Bp);
     }
     op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);

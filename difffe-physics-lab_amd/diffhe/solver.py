@@ -358,7 +358,7 @@ def _solve_forward(solver, kappa, f):
         ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
         u = torch.empty((B, n), dtype=torch.float64, device=plan.device)
         stage = None
-        if 16 * (n - 1) > 160 * 1024 - 2048:
+        if n - 1 > 10240:                                   # longer chains stage through global memory
             stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
         _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
                                           n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
@@ -426,7 +426,7 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         dk_e = torch.empty((B, m), dtype=torch.float64, device=plan.device) if want_e else None
         part = torch.empty((B, plan.n_seg), dtype=torch.float64, device=plan.device)
         stage = None
-        if 16 * (n - 1) > 160 * 1024 - 2048:
+        if n - 1 > 10240:                                   # longer chains stage through global memory
             stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
         _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(g_dev), n,
                                             _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(df), n,

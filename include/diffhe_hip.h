@@ -55,8 +55,9 @@ const char* diffhe_last_hip_error(void);
  *            (bit0: first node is Dirichlet, bit1: last node is Dirichlet)
  *   g        (n) Dirichlet values (0 at free nodes)
  *   u        (B, n) out, row stride ldu
- *   stage    optional global staging buffer, (B * n_seg) * 2 * max_seg_len doubles,
- *            used only when a segment does not fit LDS (may be NULL otherwise)
+ *   stage    global staging buffer, (B * n_seg) * 2 * (n - 1) doubles, used only when
+ *            n - 1 > 10240 (shorter chains are solved in registers; may be NULL then;
+ *            DIFFHE_E_TOOBIG if it is needed and NULL)
  * ---------------------------------------------------------------------------- */
 int diffhe_chain1d_solve(const double* x, const double* kappa, long long kappa_sb, long long kappa_se,
                          const double* rhs, long long rhs_sb, const int* seg, int n_seg, const double* g,

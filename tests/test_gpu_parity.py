@@ -727,3 +727,44 @@ def test_unstructured_mesh_amg_vs_oracle(N, B):
     assert sj.last_info.path == "ell-pcg" and rel_err(uj.numpy(), u.detach().numpy()) < RTOL_U
     if N >= 96:
         assert its_amg * 3 < sj.last_info.iterations, (its_amg, sj.last_info.iterations)
+
+
+@pytest.mark.gpu
+def test_long_chain_global_staging_path():
+    """Chains longer than 10 240 elements leave the register kernel for the globally staged one."""
+    mesh = FEMesh.line(12_345)
+    nodes, el, bn, bv = arrays(mesh)
+    B = 3
+    gen = torch.Generator().manual_seed(7)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    k = torch.tensor([0.7, 1.0, 1.9], dtype=T64, requires_grad=True)
+    fc = f.cuda().requires_grad_(True)
+    u = DifferentiableFESolver(mesh, k)(fc)
+    (0.5 * (u ** 2).sum()).backward()
+    for b in range(B):
+        ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, float(k[b]), f[b].numpy(), lambda u: u)
+        assert rel_err(u[b].detach().cpu().numpy(), ux) < RTOL_U
+        assert rel_err(fc.grad[b].cpu().numpy(), dfx) < RTOL_GRAD
+        assert abs(float(k.grad[b]) - dkx.sum()) < RTOL_GRAD * abs(dkx.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [255, 256, 257, 1024, 1025, 4096, 4097, 10240, 10241])
+def test_chain_kernel_size_boundaries(N):
+    """Each register-kernel instantiation at its largest size and the next kernel at its smallest,
+    per-element kappa, non-uniform nodes, an interior Dirichlet node and a Neumann right end."""
+    rng = np.random.default_rng(N)
+    x = (np.arange(N + 1) + np.concatenate([[0.0], rng.uniform(-0.3, 0.3, N - 1), [0.0]])) / N
+    mesh = FEMesh(nodes=torch.from_numpy(x[:, None]), elements=torch.stack([torch.arange(N), torch.arange(1, N + 1)], 1),
+                  dirichlet_nodes={0: 0.3, N // 3: -0.2})
+    nodes, el, bn, bv = arrays(mesh)
+    kap = torch.from_numpy(rng.uniform(0.5, 2.0, N)).requires_grad_(True)
+    f = torch.from_numpy(1 + 0.3 * rng.standard_normal(N + 1))
+    fc = f.cuda().requires_grad_(True)
+    u = DifferentiableFESolver(mesh, kap)(fc)
+    w = rng.standard_normal(N + 1)
+    (torch.from_numpy(w).cuda() * u).sum().backward()
+    ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, kap.detach().numpy(), f.numpy(), lambda u: w)
+    assert rel_err(u.detach().cpu().numpy(), ux) < RTOL_U
+    assert rel_err(fc.grad.cpu().numpy(), dfx) < RTOL_GRAD
+    assert rel_err(kap.grad.numpy(), dkx) < RTOL_GRAD

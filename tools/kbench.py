@@ -30,7 +30,7 @@ def chain():
     from diffhe import DifferentiableFESolver
     dev = torch.device("cuda", 0)
     mesh = FEMesh.line(10_000)
-    n, B = mesh.n_nodes, 1024
+    n, B = mesh.n_nodes, int(os.environ.get('KBENCH_B', 1024))
     plan = get_plan(mesh, dev)
     L = _hip.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -43,13 +43,13 @@ def chain():
     t = timeit(lambda: _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(f), n,
                                                          _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g), _hip.ptr(u),
                                                          n, n, B, None, st), "fwd"))
-    print(f"chain1d forward  N=10000 B=1024: {t*1e6:8.1f} us  {16 * n * B / t / 1e9:8.1f} GB/s (16n B/sample)  "
+    print(f"chain1d forward  N=10000 B={B}: {t*1e6:8.1f} us  {16 * n * B / t / 1e9:8.1f} GB/s (16n B/sample)  "
           f"{B / t:.3e} solves/s")
     t2 = timeit(lambda: _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(g), n,
                                                             _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg,
                                                             _hip.ptr(df), n, None, 0, _hip.ptr(part), n, B, None, st),
                                   "adj"))
-    print(f"chain1d adjoint  N=10000 B=1024: {t2*1e6:8.1f} us  {24 * n * B / t2 / 1e9:8.1f} GB/s (24n B/sample)  "
+    print(f"chain1d adjoint  N=10000 B={B}: {t2*1e6:8.1f} us  {24 * n * B / t2 / 1e9:8.1f} GB/s (24n B/sample)  "
           f"fwd+adj {B / (t + t2):.3e} differentiable solves/s, {40 * n * B / (t + t2) / 1e9:.1f} GB/s of 40n")
 
 
