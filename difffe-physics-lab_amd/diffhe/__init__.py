@@ -3,11 +3,15 @@
 Drop-in for the public surface of danieleschmidt/DiffFE-Physics-Lab
 (reference diffhe/__init__.py:6-12): same names, same call semantics; the solve
 itself runs in hand-written HIP kernels (libdiffhe_hip.so, include/diffhe_hip.h).
+Extras that have no reference counterpart live in submodules only
+(`diffhe.distributed`: batch sharding over ranks; `diffhe._hip`: the ctypes binding).
 """
-from .mesh import FEMesh
-from .solver import DifferentiableFESolver
-from .loss import PhysicsLoss
-from .neural import NeuralPDE
+from . import loss as _loss, mesh as _mesh, neural as _neural, solver as _solver
 
-__version__ = "0.1.0"
-__all__ = ["FEMesh", "DifferentiableFESolver", "PhysicsLoss", "NeuralPDE"]
+FEMesh = _mesh.FEMesh
+DifferentiableFESolver = _solver.DifferentiableFESolver
+PhysicsLoss = _loss.PhysicsLoss
+NeuralPDE = _neural.NeuralPDE
+
+__all__ = ("FEMesh", "DifferentiableFESolver", "PhysicsLoss", "NeuralPDE")
+__version__ = "0.1.0"          # tracks the reference release this surface mirrors
