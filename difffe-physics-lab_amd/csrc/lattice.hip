@@ -344,6 +344,15 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   return s;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id, so blocks x = k (mod 8) share one L2.
+// Give each such class a contiguous range of tiles: spatially adjacent strips (which read each other's
+// halo columns / rows) then run on the same XCD at about the same time and the halo hits its L2.
+__device__ inline int xcd_tile(int x, int gx) {
+  const int q = gx >> 3, rem = gx & 7;
+  const int k = x & 7, j = x >> 3;
+  return k * q + (k < rem ? k : rem) + j;
+}
+
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW>
 __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
                                                          const TV* __restrict__ xin, const TV* __restrict__ bvec,
@@ -354,7 +363,8 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y * kWave + lane;
-  const int rc = blockIdx.x / ncb, cb = blockIdx.x - rc * ncb;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
   const int c0w = (cb * 4 + wave) * RW;
   const int r0 = rc * TR;
   const int nyp = L.ny + 1;
@@ -497,7 +507,8 @@ __global__ __launch_bounds__(256) void mg_restrict_strip_kernel(Level F, Level C
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lb = blockIdx.y * kWave + lane;
-  const int rcn = blockIdx.x / ncb, cb = blockIdx.x - rcn * ncb;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rcn = tile / ncb, cb = tile - rcn * ncb;
   const int J0 = (cb * 4 + wave) * CW;        // first coarse column of this wave
   const int I0 = rcn * TR;                    // first coarse row of this tile
   const int I1 = (I0 + TR < C.ny + 1) ? I0 + TR : C.ny + 1;

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Reduce the two rocprofv3 PMC passes over tools/pmc_traffic.py to HBM bytes per launch.
+
+    python tools/pmc_reduce.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> [out.json]
+
+Counters are in KB.  FETCH_SIZE is doubled (gfx950 reports half of the streamed read bytes,
+MI355X_MICROARCH.md HBM section); the factor is re-checked on the two calibration kernels of known
+traffic that the script launches (a device-to-device copy and a Jacobi sweep from a zero guess).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_jacobi_kernel")
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"(void )?([^(]+)", name)
+    return (m.group(2) if m else name).strip()
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in KEEP):
+                    acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    # a name can cover launches of very different sizes (small helper copies): keep the full-size ones
+    big = {k: [x for x in v if x > 0.5 * max(v)] for k, v in acc.items()}
+    return {k: sum(v) / len(v) for k, v in big.items()}
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    log = os.path.join(os.path.dirname(sys.argv[1].rstrip("/")), os.path.basename(sys.argv[1].rstrip("/")) + ".log")
+    pass_bytes = 1024 * 1024 * 8 * 256 if not os.path.exists(log) else None
+    if pass_bytes is None:
+        for line in open(log):
+            if line.startswith("pass_bytes"):
+                pass_bytes = int(line.split()[1])
+    out = {"pass_bytes": pass_bytes, "kernels": {}}
+    for k in sorted(set(fetch) & set(write)):
+        rd, wr = 2.0 * fetch[k] * 1024.0, write[k] * 1024.0
+        out["kernels"][k] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "read_bytes_corrected": rd,
+                             "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+                             "passes": (rd + wr) / pass_bytes, "read_passes": rd / pass_bytes,
+                             "write_passes": wr / pass_bytes}
+    text = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
