@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--mesh", type=int, default=1024, help="N of the N x N mesh (bench contract: 1024)")
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU (bench contract: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (clean kernel traces)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--tol", type=float, default=None, help="override the solver's relative residual tolerance")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -122,7 +123,8 @@ def main():
 
     # secondary measurement, same run: V-cycle vectors stored in fp64 instead of fp32
     variant = None
-    if world == 1 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample":
+    if (world == 1 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample"
+            and not args.no_variants):
         solver.mg["fp32"] = 0
         step()
         torch.cuda.synchronize(dev)

@@ -148,7 +148,12 @@ enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
 //   F_PUPD:    the operand is the NEW search direction p = z + beta p_old of the CG (with M_APPLY
 //              this is "update p, apply A, dot p.Ap" in one pass); the kernel also stores p and
 //              applies the pending iterate update x += alpha_prev p_old.
-enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2 };
+//   F_RESTRICT (with M_RESID): the residual is not stored; it is restricted on the fly (P1 full
+//              weighting) into the coarse right-hand side.  The strip then covers the 2 CW + 1 fine
+//              columns 2 J0 - 1 .. 2 J0 + 2 CW - 1 that feed the wave's CW coarse columns (one fine
+//              column is shared with -- and recomputed by -- each neighbour strip) and the tile the
+//              fine rows 2 I0 - 1 .. 2 I1 - 1 of the coarse rows I0 .. I1 - 1.
+enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2, F_RESTRICT = 3 };
 
 struct Extra {
   const void* a0;           // F_PROLONG: coarse correction e (TA);  F_PUPD: z (TA)
@@ -158,8 +163,8 @@ struct Extra {
   const double* alpha;      // F_PUPD: per-sample alpha of the previous iteration
   const double* beta;       // F_PUPD
   int first;                // F_PUPD: first iteration (p = z, nothing pending)
-  int cW;                   // F_PROLONG: row width of the coarse level
-  const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there)
+  int cW;                   // F_PROLONG, F_RESTRICT: row width of the coarse level
+  const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there); F_RESTRICT: coarse flags
   const double* dotv;       // M_APPLY, F_NONE: dot (A x + addv) against this vector instead of x
   const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
 };
@@ -202,7 +207,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const TM* __restrict__ p3 = p2 + n * Bv;
   const TV* __restrict__ px = src + i0 * Bp;
   const TV* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
-  TV* __restrict__ po = out ? out + i0 * Bp : nullptr;
+  TV* __restrict__ po = (out && FUSE != F_RESTRICT) ? out + i0 * Bp : nullptr;
   const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
 
   const double inv_omega_in = XFROMB ? 1.0 / omega_in : 0.0;
@@ -268,6 +273,12 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 #pragma unroll
   for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (double)(p3 - rowV + (i64)dq[k + 1] * Bv)[lv] : 0.0;
 
+  constexpr int CWR = (FUSE == F_RESTRICT) ? (RW - 1) / 2 : 1;  // coarse columns of an F_RESTRICT strip
+  double racc[CWR], rnext[CWR];
+#pragma unroll
+  for (int j = 0; j < CWR; ++j) racc[j] = rnext[j] = 0.0;
+  const int cI0 = (r0 + 1) >> 1, cJ0 = (c0w + 1) >> 1;          // F_RESTRICT: first coarse row / column
+
   for (int row = r0; row < r1; ++row) {
     if (row + 1 < nyp) {
       load_window(row + 1, rowX, px + rowX, p0 + rowV, xp);
@@ -276,6 +287,11 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       for (int q = 0; q < RW + 2; ++q) xp[q] = 0.0;
     }
     double d0[RW], e1[RW + 1], n2c[RW], d3c[RW + 1];
+    double resrow[(FUSE == F_RESTRICT) ? RW : 1];
+    if (FUSE == F_RESTRICT) {
+#pragma unroll
+      for (int k = 0; k < RW; ++k) resrow[k] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
       d0[k] = (double)(p0 + (i64)dq[k + 1] * Bv)[lv];
@@ -292,7 +308,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
       const int q = k + 1;
-      if (TAIL && c0w + k >= W) continue;
+      if (TAIL && (c0w + k >= W || c0w + k < 0)) continue;
       double acc = d0[k] * xc[q];
       acc += e1[k + 1] * xc[q + 1] + e1[k] * xc[q - 1];
       acc += n2c[k] * xp[q] + n2p[k] * xm[q];
@@ -316,13 +332,48 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         // XFROMB: the window holds x1 = omega_in * rhs * dinv, so rhs = x1 / (omega_in * dinv)
         const double bi = XFROMB ? xc[q] * (sb * d0[k]) * inv_omega_in : (double)(pb + o)[lb];
         const double res = bi - sb * acc;
-        if (MODE == M_RESID) {
+        if (MODE == M_RESID && FUSE == F_RESTRICT) {
+          resrow[k] = res;
+        } else if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
           s += res * res;
         } else {
           const double xo = xc[q] + omega * res * dinv;
           (po + o)[lb] = (TV)xo;
           s += bi * xo;
+        }
+      }
+    }
+    if (FUSE == F_RESTRICT) {
+      // strip column k <-> fine column 2 cJ0 - 1 + k, so coarse column cJ0 + j sits at k = 2 j + 1.
+      // Full weighting of the P1 lattice: centre 1; W, E, N, S, NE-of-the-row-above, SW-of-the-row-below 1/2.
+      const bool store = (row & 1) || row + 1 >= nyp;  // coarse row complete after its odd row (or at the last row)
+      if (!(row & 1)) {
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) racc[j] += resrow[2 * j + 1] + 0.5 * (resrow[2 * j] + resrow[2 * j + 2]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) {
+          racc[j] += 0.5 * (resrow[2 * j + 1] + resrow[2 * j]);
+          rnext[j] = 0.5 * (resrow[2 * j + 1] + resrow[2 * j + 2]);
+        }
+      }
+      if (store) {
+        const int I = row >> 1;
+        if (I >= cI0) {
+#pragma unroll
+          for (int j = 0; j < CWR; ++j) {
+            const int J = cJ0 + j;
+            if (J < ex.cW) {
+              const i64 Ic = (i64)I * ex.cW + J;
+              (out + Ic * Bp)[lb] = (TV)(ex.bc[Ic] ? 0.0 : racc[j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) {
+          racc[j] = rnext[j];
+          rnext[j] = 0.0;
         }
       }
     }
@@ -365,15 +416,28 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
   const int b = blockIdx.y * kWave + lane;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int rc = tile / ncb, cb = tile - rc * ncb;
-  const int c0w = (cb * 4 + wave) * RW;
-  const int r0 = rc * TR;
   const int nyp = L.ny + 1;
-  const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+  int c0w, r0, r1;
+  bool active;
+  if (FUSE == F_RESTRICT) {  // TR counts COARSE rows, the wave owns (RW - 1) / 2 coarse columns
+    const int J0 = (cb * 4 + wave) * ((RW - 1) / 2), I0 = rc * TR;
+    const int cnyp = (nyp + 1) >> 1;
+    const int I1 = (I0 + TR < cnyp) ? I0 + TR : cnyp;
+    c0w = 2 * J0 - 1;
+    r0 = I0 > 0 ? 2 * I0 - 1 : 0;
+    r1 = (2 * I1 < nyp) ? 2 * I1 : nyp;
+    active = J0 < ex.cW && I0 < I1;
+  } else {
+    c0w = (cb * 4 + wave) * RW;
+    r0 = rc * TR;
+    r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+    active = c0w < L.W && r0 < r1;
+  }
   const double sb = scale ? scale[b] : 1.0;
   const TV* __restrict__ src = XFROMB ? bvec : xin;
   double s = 0.0;
-  if (c0w < L.W && r0 < r1) {
-    if (c0w + RW + 1 > L.W)
+  if (active) {
+    if (c0w + RW + 1 > L.W || c0w < 0)
       s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
                                                                        c0w, r0, r1);
     else
@@ -387,6 +451,7 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
 }
 
 constexpr int kStripCols = 8;
+constexpr int kRestrictCols = 4;  // coarse columns per wave of the fused residual + restriction (9 fine columns)
 constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused CG kernel: fewer VGPRs, more waves
 constexpr int kPartBlocks = 2048;  // capacity (in blocks) of every partial-sum buffer
 
@@ -494,64 +559,6 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(Level F, Level C, cons
       out = (double)r[c * Bp + nm.b] + 0.5 * h;
     }
     rc[(i64)I * Bp + nm.b] = (TV)out;
-  }
-}
-
-// Strip variant of the restriction for big levels: a wave owns CW consecutive COARSE columns
-// (2 CW fine columns + one halo column on each side) x 64 samples and marches down the coarse rows,
-// carrying the odd fine row it shares with the next coarse row in registers, so every fine value is
-// loaded ~1.25 times instead of 1.75.
-template <typename TV, int CW>
-__global__ __launch_bounds__(256) void mg_restrict_strip_kernel(Level F, Level C, const TV* __restrict__ r,
-                                                                 TV* __restrict__ rc, int Bp, int ncb, int TR) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned lb = blockIdx.y * kWave + lane;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int rcn = tile / ncb, cb = tile - rcn * ncb;
-  const int J0 = (cb * 4 + wave) * CW;        // first coarse column of this wave
-  const int I0 = rcn * TR;                    // first coarse row of this tile
-  const int I1 = (I0 + TR < C.ny + 1) ? I0 + TR : C.ny + 1;
-  if (J0 >= C.W || I0 >= I1) return;
-  constexpr int NW = 2 * CW + 1;              // fine window columns 2*J0 - 1 .. 2*J0 + 2*CW - 1
-  int dq[NW];
-  bool ok[NW];
-#pragma unroll
-  for (int q = 0; q < NW; ++q) {
-    int c = 2 * J0 - 1 + q;
-    ok[q] = c >= 0 && c < F.W;
-    c = c < 0 ? 0 : (c > F.W - 1 ? F.W - 1 : c);
-    dq[q] = c;
-  }
-  auto load_row = [&](int fi, double* dst) {
-    const bool rowok = fi >= 0 && fi <= F.ny;
-    const TV* __restrict__ row = r + (i64)(rowok ? fi : 0) * F.W * Bp;
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-      const double v = (double)(row + (i64)dq[q] * Bp)[lb];
-      dst[q] = (rowok && ok[q]) ? v : 0.0;
-    }
-  };
-  double up[NW], mid[NW], dn[NW];
-  load_row(2 * I0 - 1, up);
-  for (int I = I0; I < I1; ++I) {
-    load_row(2 * I, mid);
-    load_row(2 * I + 1, dn);
-#pragma unroll
-    for (int k = 0; k < CW; ++k) {
-      const int J = J0 + k;
-      if (J < C.W) {
-        const int q = 2 * k + 1;  // window index of fine column 2J
-        // centre + 1/2 (W, E, N, S, NE-of-previous-row, SW-of-next-row)
-        double out = mid[q] + 0.5 * (mid[q - 1] + ((q + 1 < NW) ? mid[q + 1] : 0.0) + up[q] + dn[q] +
-                                      ((q + 1 < NW) ? up[q + 1] : 0.0) + dn[q - 1]);
-        const i64 Ic = (i64)I * C.W + J;
-        if (C.bc[Ic]) out = 0.0;
-        (rc + Ic * Bp)[lb] = (TV)out;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NW; ++q) up[q] = dn[q];
   }
 }
 
@@ -921,19 +928,24 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     }
     cur[l] = a;
     if (l < last) {
-      op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
       const Level& C = H.lev[l + 1];
       if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
-        constexpr int CW = 8;
-        const int ncb = (C.W + 4 * CW - 1) / (4 * CW);
-        int nrc = (4096 + ncb * (H.Bp / kWave) - 1) / (ncb * (H.Bp / kWave));
+        // residual + full-weighting restriction in one pass: the residual is never stored
+        constexpr int CW = kRestrictCols;
+        StripGeom g{true, 0, 0, 0};
+        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
+        int nrc = (6144 + g.ncb * (H.Bp / kWave) - 1) / (g.ncb * (H.Bp / kWave));
         if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
         if (nrc < 1) nrc = 1;
-        const int TR = (C.ny + 1 + nrc - 1) / nrc;
-        nrc = (C.ny + 1 + TR - 1) / TR;
-        hipLaunchKernelGGL((mg_restrict_strip_kernel<TV, CW>), dim3(ncb * nrc, H.Bp / kWave), dim3(256), 0, st, L, C,
-                           (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp, ncb, TR);
+        g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+        g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+        Extra ex{};
+        ex.cW = C.W;
+        ex.bc = C.bc;
+        launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, (const TV*)a, rhs[l],
+                                                                       (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
       } else {
+        op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
         LAUNCH(mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
       }
       rhs[l + 1] = (const TV*)H.rhs[l + 1];

@@ -18,13 +18,13 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 0, 2", "fused CG step, z/p fp64", 6.0),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
     ("dia_strip_kernel<float, float, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp32)", 1.0),
+    ("dia_strip_kernel<float, float, double, 1, 3", "residual + restriction, residual never stored (fp32)", 1.125),
     ("dia_strip_kernel<float, float, double, 1, 0", "residual (fp32)", 1.5),
-    ("mg_restrict_strip_kernel<float", "restriction (fp32)", 0.625),
     ("dia_strip_kernel<float, float, double, 2, 1", "prolong + correct + Jacobi sweep (fp32)", 1.625),
     ("dia_strip_kernel<float, float, double, 2, 0, 3, true, false", "Jacobi sweep (fp32)", 1.5),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp64)", 2.0),
+    ("dia_strip_kernel<double, double, double, 1, 3", "residual + restriction (fp64)", 2.25),
     ("dia_strip_kernel<double, double, double, 1, 0", "residual (fp64)", 3.0),
-    ("mg_restrict_strip_kernel<double", "restriction (fp64)", 1.25),
     ("dia_strip_kernel<double, double, double, 2, 1", "prolong + correct + Jacobi sweep (fp64)", 3.25),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, false", "Jacobi sweep (fp64)", 3.0),
     ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),
