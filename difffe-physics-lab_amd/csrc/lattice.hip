@@ -167,6 +167,7 @@ struct Extra {
   const unsigned char* bc;  // F_PROLONG: fine Dirichlet flags (no correction there); F_RESTRICT: coarse flags
   const double* dotv;       // M_APPLY, F_NONE: dot (A x + addv) against this vector instead of x
   const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
+  float* r32;               // M_RESID, F_NONE, fp64 vectors: also store the residual rounded to fp32 (may be NULL)
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
@@ -336,6 +337,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           resrow[k] = res;
         } else if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
+          if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) (ex.r32 + ((i64)row * W + c0w + k) * Bp)[lb] = (float)res;
           s += res * res;
         } else {
           const double xo = xc[q] + omega * res * dinv;
@@ -628,8 +630,10 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict_
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double bi = bvec[o];
-    x[o] = 0.0;
-    r[o] = bi;
+    if (x) {  // x == NULL (full-multigrid start): x and r are set after the start, only b.b and the fp32 copy are due
+      x[o] = 0.0;
+      r[o] = bi;
+    }
     if (r32) r32[o] = (float)bi;
     s += bi * bi;
   }
@@ -1109,7 +1113,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
 
   int nbz = 0, nba = 0;
-  LAUNCH(pcg_init_kernel, n, b, x, r, r32, partA, n, Bp);
+  const bool light_init = use_fmg && f32;  // the start overwrites x and r; it reads b through r32
+  LAUNCH(pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, r32, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
   // Fused loop (fine level runs the strip kernels): per iteration
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
@@ -1151,8 +1156,15 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       if (!x0) return DIFFHE_E_LAUNCH;
       LAUNCH(pcg_setx_kernel<double>, n, x0, x, n, Bp);
     }
-    op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
-    if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, r32, n, Bp);
+    const StripGeom gr = strip_geom(L0, Bp);
+    if (gr.use && f32) {  // r = b - A x and its fp32 copy in one pass
+      Extra ex{};
+      ex.r32 = r32;
+      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, nullptr, Bp, gr, st, ex);
+    } else {
+      op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
+      if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, r32, n, Bp);
+    }
   }
   precondition(1);
   rc = diffhe::check_launch();
