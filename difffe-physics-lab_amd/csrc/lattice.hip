@@ -168,6 +168,9 @@ struct Extra {
   const double* dotv;       // M_APPLY, F_NONE: dot (A x + addv) against this vector instead of x
   const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
   float* r32;               // M_RESID, F_NONE, fp64 vectors: also store the residual rounded to fp32 (may be NULL)
+  const double* sub;        // M_APPLY, F_NONE: y = A x - sub_scale[b] * sub[i], sub batch-shared (n) (may be NULL)
+  const double* sub_scale;  //   per-sample factor of `sub` (NULL: 1)
+  const unsigned char* mask;  // M_APPLY, F_NONE: rows with mask[i] != 0 are stored as 0 (may be NULL)
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
@@ -212,6 +215,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const i64 rowV = (i64)W * Bv, rowX = (i64)W * Bp;
 
   const double inv_omega_in = XFROMB ? 1.0 / omega_in : 0.0;
+  const double sub_fac = (MODE == M_APPLY && FUSE == F_NONE && ex.sub && ex.sub_scale) ? ex.sub_scale[b] : 1.0;
   const double beta = (FUSE == F_PUPD && !ex.first) ? ex.beta[b] : 0.0;
   const double alpha_prev = (FUSE == F_PUPD && !ex.first) ? ex.alpha[b] : 0.0;
   const TA* __restrict__ aux = (const TA*)ex.a0;
@@ -316,7 +320,12 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       if (ND == 4) acc += d3c[k] * xp[q - 1] + d3p[k + 1] * xm[q + 1];
       const i64 o = (i64)k * Bp;
       if (MODE == M_APPLY) {
-        const double y = sb * acc;
+        double y = sb * acc;
+        if (FUSE == F_NONE && (ex.sub || ex.mask)) {  // load vector of a lattice mesh: F = M f - lift, 0 on Dirichlet rows
+          const i64 ig = (i64)row * W + c0w + k;
+          if (ex.sub) y -= sub_fac * ex.sub[ig];
+          if (ex.mask && ex.mask[ig]) y = 0.0;
+        }
         if (po) (po + o)[lb] = (TV)y;
         if (FUSE == F_NONE && ex.dotv) {  // bilinear form lam^T (A x + add): dL/dkappa of a factored operator
           const i64 ig = (i64)row * W + c0w + k;
@@ -620,6 +629,37 @@ __global__ __launch_bounds__(256) void mg_restrict_kappa_kernel(const double* __
   }
 }
 
+
+// Gershgorin bound of D^-1 A: max over rows (and samples) of sum_j |a_ij| / a_ii, as the bit pattern of a
+// non-negative double (ordered like an unsigned integer, so atomicMax gives a deterministic result).
+// Meshes with obtuse triangles have positive off-diagonal entries and a spectrum that reaches beyond 2.
+__global__ __launch_bounds__(256) void dia_gershgorin_kernel(Level L, int Bv, unsigned long long* __restrict__ out) {
+  const NodeMap nm = node_map(Bv);
+  const i64 n = L.n;
+  double m = 0.0;
+  if (nm.b < Bv) {
+    for (int i = nm.node0; i < L.n; i += nm.stride) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        if (k < L.nd) {
+          const int off = dia_off(L, k);
+          if (i + off < L.n) sum += fabs(L.v[((i64)k * n + i) * Bv + nm.b]);
+          if (i - off >= 0) sum += fabs(L.v[((i64)k * n + (i - off)) * Bv + nm.b]);
+        }
+      }
+      const double r = 1.0 + sum / L.v[(i64)i * Bv + nm.b];
+      m = r > m ? r : m;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double o = __shfl_xor(m, d);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 // ---- CG vector kernels ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
                                                         double* __restrict__ r, float* __restrict__ r32,
@@ -793,6 +833,7 @@ struct Hier {
   const double* scale;
   double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
   int nu, n_coarse, fmg_coarse_cycles;
+  double coarse_lmax;  // upper bound of the spectrum of D^-1 A on the coarsest level (2 for an M-matrix)
   // per-level work vectors
   void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
   void *bF[kMaxLevels], *xF[kMaxLevels];  // full-multigrid start: restricted right-hand sides, iterates
@@ -869,7 +910,7 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   const Level& L = H.lev[l];
   const double pi = 3.14159265358979323846;
   const double lmin = 0.5 * (0.5 * (1.0 - cos(pi / L.nx)) + 0.5 * (1.0 - cos(pi / L.ny)));
-  const double lmax = 2.0;
+  const double lmax = H.coarse_lmax;
   int deg = (int)ceil(1.5 * sqrt(lmax / lmin));
   if (deg < H.n_coarse) deg = H.n_coarse;
   if (deg > 400) deg = 400;
@@ -1041,6 +1082,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
+  H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
@@ -1108,6 +1150,20 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.active = (int*)(sc + 5 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 6 * Bp);
+  {  // spectrum bound for the coarsest-level Chebyshev solve: 2 unless the mesh has obtuse triangles
+    const Level& Lc = H.lev[H.nl - 1];
+    if (Lc.nd == 4) {
+      unsigned long long* gb = (unsigned long long*)(sc + 8 * Bp);
+      rc = diffhe::check(hipMemsetAsync(gb, 0, sizeof(unsigned long long), st));
+      if (rc) return rc;
+      hipLaunchKernelGGL(dia_gershgorin_kernel, node_grid(Lc.n, Bv, 256), dim3(256), 0, st, Lc, Bv, gb);
+      double bound = 0.0;
+      rc = diffhe::check(hipMemcpyAsync(&bound, gb, sizeof(double), hipMemcpyDeviceToHost, st));
+      if (!rc) rc = diffhe::check(hipStreamSynchronize(st));
+      if (rc) return rc;
+      if (bound > 2.0 && bound < 1e3) H.coarse_lmax = bound * (1.0 + 1e-9);
+    }
+  }
   const dim3 sgrid((Bp + 63) / 64);
 #define SCALAR(phase, part, nb_) \
   hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
@@ -1283,6 +1339,14 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   Level L;
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
+  const StripGeom g = strip_geom(L, Bp);
+  if (g.use && (!sub || sub_B == 1)) {
+    Extra ex{};
+    ex.sub = sub; ex.sub_scale = sub_scale; ex.mask = mask;
+    launch_strip<double, M_APPLY, false>(L, 1, nullptr, x, (const double*)nullptr, y, 0.0, 0.0, nullptr, Bp, g,
+                                         (hipStream_t)stream, ex);
+    return diffhe::check_launch();
+  }
   hipLaunchKernelGGL(dia_shared_apply_kernel, lgrid(L.n, Bp), dim3(256), 0, (hipStream_t)stream, L, x, sub, sub_B,
                      sub_scale, mask, y, Bp);
   return diffhe::check_launch();

@@ -358,17 +358,23 @@ def test_2d_64_batch_vs_oracle(method):
         assert abs(float(kt.grad[b]) - dko.sum()) <= RTOL_GRAD * abs(dko.sum())
 
 
+@pytest.mark.parametrize("shape", [(202, 70, 0.35), (203, 70, 1.5), (40, 48, 1.5)])
 @pytest.mark.parametrize("graded", [False, True])
-def test_lattice_strip_kernels_batch64(graded):
-    """Batch >= 64 and a grid >= 32 rows: the register-window strip kernels are the ones that
-    run (fine level) -- per-sample scalar kappa (shared matrix + scale) and per-sample
-    per-element kappa (matrix per sample), right-angled (3 diagonals) and skewed (4)."""
-    nx, ny = 40, 48
-    base = FEMesh.rectangle(nx, ny, (0.0, 1.0), (0.0, 1.5), 0.2)
+def test_lattice_strip_kernels_batch64(graded, shape):
+    """Batch >= 64 on a grid of >= 192 columns and >= 64 rows: the register-window strip kernels
+    (fused first sweeps, fused residual + restriction, fused prolongation, fused CG step, strip load
+    vector) are the ones that run on the fine level -- per-sample scalar kappa (shared matrix + scale)
+    and per-sample per-element kappa (matrix per sample), right-angled (3 diagonals) and skewed (4),
+    non-zero Dirichlet data, a width that is not a multiple of the strip width.  Shape (202, 70) has square
+    cells and halves once (full coarsening with the fused transfer kernels); (203, 70) cannot be coarsened,
+    so its single level is solved by the Chebyshev semi-iteration alone -- on the skewed mesh (obtuse
+    triangles, spectrum of D^-1 A beyond 2) that needs the Gershgorin bound of the coarsest operator."""
+    nx, ny, yr = shape
+    base = FEMesh.rectangle(nx, ny, (0.0, 1.0), (0.0, yr), 0.2)
     rng = np.random.default_rng(21)
     xy = base.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
     if graded:
-        xy[1:-1, 1:-1] += rng.uniform(-0.2, 0.2, (ny - 1, nx - 1, 2)) * np.array([1.0 / nx, 1.5 / ny])
+        xy[1:-1, 1:-1] += rng.uniform(-0.2, 0.2, (ny - 1, nx - 1, 2)) * np.array([1.0 / nx, yr / ny])
     mesh = FEMesh(nodes=torch.from_numpy(xy.reshape(-1, 2)), elements=base.elements,
                   dirichlet_nodes=dict(base.dirichlet_nodes))
     nodes, el, bn, bv = arrays(mesh)
