@@ -26,9 +26,14 @@ for case in range(n_cases):
         nx, ny = (int(rng.integers(2, 70)), int(rng.integers(2, 70))) if not LARGE else \
             (int(rng.integers(190, 420)), int(rng.integers(64, 300)))
         mesh = FEMesh.rectangle(nx, ny, (0.0, float(rng.uniform(0.5, 6.0))), (0.0, 1.0), float(rng.uniform(-1, 1)))
+        if rng.random() < 0.5:     # skewed lattice: jittered interior nodes (4 diagonals, some obtuse triangles)
+            xy = mesh.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
+            hx, hy = xy[0, 1, 0] - xy[0, 0, 0], xy[1, 0, 1] - xy[0, 0, 1]
+            xy[1:-1, 1:-1] += rng.uniform(-0.25, 0.25, (ny - 1, nx - 1, 2)) * np.array([hx, hy])
+            mesh = FEMesh(torch.from_numpy(xy.reshape(-1, 2)), mesh.elements, dict(mesh.dirichlet_nodes))
         if kind == "rect_bc":      # Dirichlet only on part of the boundary (+ one interior node): Neumann elsewhere
             keys = list(mesh.dirichlet_nodes)
-            keep = [k for k in keys if mesh.nodes[k, 0] == 0.0] + [int(rng.integers(0, mesh.n_nodes))]
+            keep = [k for k in keys if abs(float(mesh.nodes[k, 0])) < 1e-12] + [int(rng.integers(0, mesh.n_nodes))]
             mesh.dirichlet_nodes = {k: float(rng.uniform(-1, 1)) for k in keep}
         if kind == "unstructured":
             perm = rng.permutation(mesh.n_nodes)
