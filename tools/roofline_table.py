@@ -28,10 +28,13 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 2, 1", "prolong + correct + Jacobi sweep (fp64)", 3.25),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, false", "Jacobi sweep (fp64)", 3.0),
     ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),
-    ("pcg_init_kernel", "x = 0, r = b, b.b", 3.5),
+    ("pcg_init_kernel", "b.b and fp32 copy of b (x, r are set after the full-multigrid start)", 1.5),
     ("to_node_major_kernel", "(B,n) -> (n,Bp)", 2.0),
     ("to_sample_major_kernel", "(n,Bp) -> (B,n)", 2.0),
     ("dia_shared_apply_kernel", "F = M f - lift", 2.0),
+    ("dia_strip_kernel<double, double, double, 0, 0, 4", "F = M f - lift (strip kernel)", 2.0),
+    ("dia_strip_kernel<double, double, double, 0, 0, 3", "dL/dkappa bilinear form lambda^T K_1 u", 2.0),
+    ("pcg_setx_kernel", "x = x0 (fp32 -> fp64)", 1.5),
 ]
 
 
