@@ -710,12 +710,36 @@ __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, T
 }
 
 template <typename TV>
-__global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, double* __restrict__ x, int n, int Bp) {
+__global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, double* __restrict__ x,
+                                                        double* __restrict__ part, int n, int Bp) {
+  __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
+  double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    x[o] = (double)x0[o];
+    const double v = (double)x0[o];
+    x[o] = v;
+    s += v * v;
   }
+  if (part) STORE_PARTIAL(part, s);  // |x0|^2: scale of the attainable residual (S_FLOOR)
+}
+
+// Per-sample max of the matrix diagonal (bit pattern of a non-negative double, atomicMax: deterministic).
+// out has Bv entries, zeroed by the caller.
+__global__ __launch_bounds__(256) void dia_maxdiag_kernel(Level L, int Bv, unsigned long long* __restrict__ out) {
+  const NodeMap nm = node_map(Bv);
+  double m = 0.0;
+  if (nm.b < Bv)
+    for (int i = nm.node0; i < L.n; i += nm.stride) {
+      const double d = L.v[(i64)i * Bv + nm.b];
+      m = d > m ? d : m;
+    }
+  const int LB = Bv < kWave ? Bv : kWave;
+  for (int off = LB; off < kWave; off <<= 1) {  // lanes that hold the same sample
+    const double o = __shfl_xor(m, off);
+    m = o > m ? o : m;
+  }
+  if ((int)(threadIdx.x & 63) < LB && nm.b < Bv) atomicMax(out + nm.b, (unsigned long long)__double_as_longlong(m));
 }
 
 __global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__ r, float* __restrict__ r32, int n, int Bp) {
@@ -753,9 +777,12 @@ __global__ __launch_bounds__(256) void pcg_update_p_kernel(const TV* __restrict_
 // ---- per-sample scalars -----------------------------------------------------------------------
 struct PcgScalars {
   double *rz, *alpha, *beta, *bb, *tol2;
+  const double* maxdiag;  // S_FLOOR: per-sample (Bv entries) max diagonal of the unscaled level-0 matrix
+  const double* scale;    // S_FLOOR: per-sample operator scale (may be NULL)
+  int Bv;
   int *active, *iters, *n_active;
 };
-enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6 };
+enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6, S_FLOOR = 7 };
 
 // 1024 threads: lanes over samples, 16 waves over slices of the partial list (fixed order)
 __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const double* __restrict__ part, int nblk, int Bp,
@@ -819,6 +846,15 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
     case S_SUM:  // plain per-sample total
       relres[b] = a;
       break;
+    case S_FLOOR: {  // a = |x0|^2.  fp64 cannot bring |b - A x| below ~ u |A| |x| (u = 2^-53): the recurrence
+      // residual keeps falling past that level but the iterate no longer improves, so the stop is floored at
+      // HALF of it -- the backward-stability level a direct fp64 solve (the reference's LU) reaches too.
+      const double anorm = 2.0 * S.maxdiag[S.Bv == 1 ? 0 : b] * (S.scale ? S.scale[b] : 1.0);  // >= |A|_inf
+      const double fl = 0.5 * 1.1102230246251565e-16 * anorm;
+      const double floor2 = fl * fl * a;
+      if (floor2 > S.tol2[b]) S.tol2[b] = floor2;
+      break;
+    }
     default:  // S_RELRES: a = |b - A x|^2
       relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
   }
@@ -1150,6 +1186,16 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.active = (int*)(sc + 5 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 6 * Bp);
+  const bool use_floor = (precond_fp32 & 16) == 0;  // bit 4 set: stop on `tol` alone
+  S.maxdiag = sc + 9 * Bp;  // Bv entries (Bv <= Bp)
+  S.scale = scale;
+  S.Bv = Bv;
+  if (use_floor && use_fmg) {
+    rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));
+    if (rc) return rc;
+    hipLaunchKernelGGL(dia_maxdiag_kernel, node_grid(L0.n, Bv, 512), dim3(256), 0, st, L0, Bv,
+                       (unsigned long long*)S.maxdiag);
+  }
   {  // spectrum bound for the coarsest-level Chebyshev solve: 2 unless the mesh has obtuse triangles
     const Level& Lc = H.lev[H.nl - 1];
     if (Lc.nd == 4) {
@@ -1206,12 +1252,13 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     if (f32) {
       const float* x0 = fmg_start<float>(H, (const float*)r32, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<float>, n, x0, x, n, Bp);
+      LAUNCH(pcg_setx_kernel<float>, n, x0, x, use_floor ? partA : (double*)nullptr, n, Bp);
     } else {
       const double* x0 = fmg_start<double>(H, b, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<double>, n, x0, x, n, Bp);
+      LAUNCH(pcg_setx_kernel<double>, n, x0, x, use_floor ? partA : (double*)nullptr, n, Bp);
     }
+    if (use_floor) SCALAR(S_FLOOR, partA, nblk);
     const StripGeom gr = strip_geom(L0, Bp);
     if (gr.use && f32) {  // r = b - A x and its fp32 copy in one pass
       Extra ex{};

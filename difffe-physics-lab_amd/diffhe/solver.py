@@ -251,7 +251,8 @@ class _Engine:
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               min(self.max_iter, 500), len(omegas), mg["n_coarse"], om,
                                               int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
-                                              | ((int(mg.get("fmg_cycles", 1)) - 1) << 2), _hip.ptr(work),
+                                              | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
+                                              | ((0 if int(mg.get("floor", 1)) else 1) << 4), _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
                                               _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
@@ -583,7 +584,8 @@ class DifferentiableFESolver(nn.Module):
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)
-        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1, fmg=1)
+        # floor = 1: the stop is `tol` or half the residual level fp64 can attain (u |A| |x|), whichever is larger
+        self.mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1, fmg=1, floor=1)
         for item in filter(None, os.environ.get("DIFFHE_MG", "").split(",")):   # e.g. "nu=1,omega=0.85"
             key, val = item.split("=")
             if key == "omegas":

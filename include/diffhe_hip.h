@@ -204,7 +204,13 @@ typedef struct diffhe_mg_level {
  *   precond_fp32  bit 0: the V-cycle AND the CG search direction p are stored in fp32 (arithmetic
  *            stays fp64 in registers; x, r, Ap and all dot products are fp64, and every update
  *            uses the stored p, so the recursion r = b - A x stays exact);
- *            bit 1: start the CG from a full-multigrid iterate instead of 0
+ *            bit 1: start the CG from a full-multigrid iterate x0 instead of 0;
+ *            bits 2-3: extra V-cycles per coarse level of that start (0..3);
+ *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at
+ *            |r| <= max(tol |b|, 0.5 u |A_b| |x0_b|), u = 2^-53, |A_b| = 2 scale[b] max_i K_ii: fp64 cannot
+ *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the
+ *            iterate no longer improves (the same backward error a direct fp64 solve, solver.py:174, reaches)
+ *   tol      relative residual |r|_2 / |b|_2 per sample
  *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */

@@ -774,3 +774,31 @@ def test_chain_kernel_size_boundaries(N):
     assert rel_err(u.detach().cpu().numpy(), ux) < RTOL_U
     assert rel_err(fc.grad.cpu().numpy(), dfx) < RTOL_GRAD
     assert rel_err(kap.grad.numpy(), dkx) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+def test_attainable_accuracy_floor_of_the_stopping_test():
+    """On a smooth right-hand side the fp64 residual stagnates near u |A| |x| / |b| (> tol for fine meshes): the
+    default stop is floored at half that level.  It must save iterations, not accuracy: the error against the
+    EXACT solution of the discrete system (DST-I) stays the one of the un-floored solve."""
+    N, B = 512, 64
+    mesh = FEMesh.rectangle(N, N)
+    dev = torch.device("cuda", 0)
+    kappa = torch.linspace(0.5, 2.0, B, dtype=T64, device=dev)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=dev)
+    nodes, el, bn, bv = arrays(mesh)
+    F = orc.load_vector(nodes, el, np.ones(mesh.n_nodes)).reshape(N + 1, N + 1)[1:-1, 1:-1]
+    out = {}
+    for floor in (1, 0):
+        solver = DifferentiableFESolver(mesh, kappa, mg=dict(floor=floor))
+        u = solver(f)
+        assert solver.last_info.not_converged == 0
+        errs = []
+        for b in (0, B - 1):
+            ue = np.zeros((N + 1, N + 1))
+            ue[1:-1, 1:-1] = _dst_solve_unit_square(N, float(kappa[b]), F)
+            errs.append(rel_err(u[b].cpu().numpy(), ue.ravel()))
+        out[floor] = (solver.last_info.iterations, max(errs))
+    assert out[1][0] <= out[0][0]                     # never more iterations
+    assert out[1][1] < RTOL_U and out[0][1] < RTOL_U
+    assert out[1][1] < 3 * out[0][1] + 1e-12          # and the same accuracy
