@@ -326,7 +326,12 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           if (ex.sub) y -= sub_fac * ex.sub[ig];
           if (ex.mask && ex.mask[ig]) y = 0.0;
         }
-        if (po) (po + o)[lb] = (TV)y;
+        if (po) {
+          // CG-step streams (Ap, p, x) are touched once per iteration, 1-2 GB each: nontemporal accesses keep them
+          // from evicting the halo columns and the V-cycle's vectors from L2 / Infinity Cache (fused step -4 %)
+          if (FUSE == F_PUPD) __builtin_nontemporal_store((TV)y, &(po + o)[lb]);
+          else (po + o)[lb] = (TV)y;
+        }
         if (FUSE == F_NONE && ex.dotv) {  // bilinear form lam^T (A x + add): dL/dkappa of a factored operator
           const i64 ig = (i64)row * W + c0w + k;
           s += (y + (ex.addv ? ex.addv[ig] : 0.0)) * (ex.dotv + ig * Bp)[lb];
@@ -334,8 +339,11 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           s += y * xc[q];
         }
         if (FUSE == F_PUPD) {  // store the new direction; apply the pending x += alpha_prev * p_old
-          (ppo + o)[lb] = (TA)xc[q];
-          if (!ex.first) (pxx + o)[lb] += alpha_prev * (double)(ppi + o)[lb];
+          __builtin_nontemporal_store((TA)xc[q], &(ppo + o)[lb]);
+          if (!ex.first) {
+            double* xa_ = &(pxx + o)[lb];
+            __builtin_nontemporal_store(__builtin_nontemporal_load(xa_) + alpha_prev * (double)(ppi + o)[lb], xa_);
+          }
         }
       } else {
         const double dinv = (MODE == M_JACOBI) ? fast_rcp(sb * d0[k]) : 0.0;
@@ -691,9 +699,9 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     if (x) x[o] += a * p[o];  // x == NULL: the iterate update is fused into the next operator apply
-    const double ri = r[o] - a * Ap[o];
-    r[o] = ri;
-    if (r32) r32[o] = (float)ri;
+    const double ri = __builtin_nontemporal_load(r + o) - a * __builtin_nontemporal_load(Ap + o);
+    __builtin_nontemporal_store(ri, r + o);
+    if (r32) r32[o] = (float)ri;  // read again right away by the V-cycle: left cacheable
     s += ri * ri;
   }
   STORE_PARTIAL(part, s);
