@@ -280,6 +280,9 @@ def main():
                                       "per-element log-normal kappa field per sample, ")
                                    + "f=1, L=mean_b sum u^2, fwd+adjoint", "mesh": f"{N}x{N}", "batch_per_gpu": B,
                        "global_batch": B * world, "solver": solver.last_info.path, "tol": solver.tol,
+                       "stop": ("per sample |r| <= max(tol |b|, 0.5 u |A| |x0|): tol, floored at half the residual level "
+                                "fp64 can attain (true residual of this workload stalls at ~3e-11 |b|)"
+                                if solver.mg.get("floor", 1) else "per sample |r| <= tol |b|"),
                        "multigrid": {k: v for k, v in solver.mg.items() if v is not None},
                        "operator": ("K_b = kappa_b * K_1: one shared matrix + a per-sample scale; every sample is "
                                     "solved by its own PCG (no u(1)/kappa shortcut); per-element-field figure in "
