@@ -32,9 +32,12 @@ class NeuralPDE(nn.Module):
 
     def forward(self, x: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Network value at the mesh nodes (or at `x` (n, dim)), zero on Dirichlet nodes."""
-        x = (self.mesh.nodes if x is None else x).double()
+        dev = self.net[0].weight.device          # the module may have been moved (model.cuda()): follow it
+        x = (self.mesh.nodes if x is None else x).to(dev, torch.float64)
         raw = self.net(x).squeeze(1)
-        return self._mask.to(x.device) * raw
+        if self._mask.device != dev:
+            self._mask = self._mask.to(dev)
+        return self._mask * raw
 
     def _compute_mask(self) -> torch.Tensor:
         """0 on Dirichlet nodes, ~1 inside (reference neural.py:80-101): in 1D the

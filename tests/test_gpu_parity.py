@@ -802,3 +802,34 @@ def test_attainable_accuracy_floor_of_the_stopping_test():
     assert out[1][0] <= out[0][0]                     # never more iterations
     assert out[1][1] < RTOL_U and out[0][1] < RTOL_U
     assert out[1][1] < 3 * out[0][1] + 1e-12          # and the same accuracy
+
+
+@pytest.mark.gpu
+def test_neural_pde_trains_on_the_device():
+    """with the module moved to the GPU the whole train_pde loop (network, mask, FEM target
+    from the HIP solver, loss, Adam) runs there without host round trips in the loop."""
+    from diffhe import NeuralPDE
+    torch.manual_seed(0)
+    mesh = FEMesh.rectangle(12, 12)
+    model = NeuralPDE(mesh, hidden_dim=16, n_layers=2).cuda()
+    losses = model.train_pde(lambda xy: torch.ones(xy.shape[0], dtype=T64, device=xy.device), n_epochs=300, lr=5e-3,
+                             mode="fem_match", verbose=False)
+    u = model()
+    assert u.is_cuda and losses[-1] < 0.2 * losses[0]
+    bc = torch.as_tensor(list(mesh.dirichlet_nodes.keys()), device=u.device)
+    assert float(u[bc].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_2d_second_order_convergence():
+    """2D analogue of reference tests/test_fem.py:114-132 (on the reference's roadmap, README.md:139-143): for
+    -lap u = 2 pi^2 sin(pi x) sin(pi y) on the unit square the nodal max error falls ~4x per mesh doubling."""
+    errs = []
+    for N in (16, 32, 64, 128):
+        mesh = FEMesh.rectangle(N, N)
+        x, y = mesh.nodes[:, 0], mesh.nodes[:, 1]
+        exact = torch.sin(math.pi * x) * torch.sin(math.pi * y)
+        u = DifferentiableFESolver(mesh)(2 * math.pi ** 2 * exact)
+        errs.append(float((u.cpu() - exact).abs().max()))
+    for a, b in zip(errs, errs[1:]):
+        assert 3.3 < a / b < 4.7
