@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
 }
 
 constexpr int kStripCols = 8;
-constexpr int kRestrictCols = 4;  // coarse columns per wave of the fused residual + restriction (9 fine columns)
+constexpr int kRestrictCols = 2;  // coarse columns per wave of the fused residual + restriction (5 fine columns; 3, 4, 6: slower)
 constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused CG kernel: fewer VGPRs, more waves
 constexpr int kPartBlocks = 2048;  // capacity (in blocks) of every partial-sum buffer
 
