@@ -470,6 +470,10 @@ __global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* _
 }
 
 constexpr int kStripCols = 8;
+// fp32-stored V-cycle vectors run best on 4-column strips (kernel trace, same box: prolongation + sweep -7 %,
+// first two sweeps -5 % against 8 columns); fp64 vectors keep 8 (half the register footprint per column there)
+template <typename TV>
+constexpr int strip_cols() { return sizeof(TV) == 4 ? 4 : kStripCols; }
 constexpr int kRestrictCols = 2;  // coarse columns per wave of the fused residual + restriction (5 fine columns; 3, 4, 6: slower)
 constexpr int kPupdCols = 4;  // narrower strips for the 3-stream fused CG kernel: fewer VGPRs, more waves
 constexpr int kPartBlocks = 2048;  // capacity (in blocks) of every partial-sum buffer
@@ -895,9 +899,10 @@ template <typename TV>
 int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, double omega, double* part,
               hipStream_t st) {
   const Level& L = H.lev[l];
-  const StripGeom g = strip_geom(L, H.Bp);
+  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
   if (g.use && xin) {
-    launch_strip<TV, M_JACOBI, false>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part, H.Bp, g, st);
+    launch_strip<TV, M_JACOBI, false, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part,
+                                                                   H.Bp, g, st);
     return g.ncb * g.nrc;
   }
   LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, xin, xout, omega, part, H.Bp);
@@ -909,9 +914,10 @@ template <typename TV>
 int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double w0, double w1, double* part,
                      TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
-  const StripGeom g = strip_geom(L, H.Bp);
+  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
   if (g.use) {
-    launch_strip<TV, M_JACOBI, true>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0, part, H.Bp, g, st);
+    launch_strip<TV, M_JACOBI, true, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0,
+                                                                  part, H.Bp, g, st);
     *result = xa;
     return g.ncb * g.nrc;
   }
@@ -1046,13 +1052,14 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = cur[l];
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
-    const StripGeom g = strip_geom(L, H.Bp);
+    const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
     if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
-      launch_strip<TV, M_JACOBI, false, F_PROLONG, TV>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2, H.omega[H.nu - 1], 0.0,
-                                                        lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      launch_strip<TV, M_JACOBI, false, F_PROLONG, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2,
+                                                                          H.omega[H.nu - 1], 0.0,
+                                                                          lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
       if (lastsweep && rz_blocks) *rz_blocks = g.ncb * g.nrc;
       TV* t = a; a = b2; b2 = t;
       s0 = 1;
