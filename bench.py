@@ -168,8 +168,9 @@ def main():
         roof = None
         traffic = None
         copy_gbs = None
-        roofline_ok = (solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample") or \
-            solver.last_info.path == "ell-pcg"
+        # the fused CG step (and its roofline entry) exists for wave-sized batches on strip-sized meshes only
+        roofline_ok = (solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample" and Bp >= 64
+                       and N >= 191) or solver.last_info.path == "ell-pcg"
         st = torch.cuda.current_stream(dev).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -184,7 +185,7 @@ def main():
             return e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
 
         other = None
-        if solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample":
+        if roofline_ok and solver.last_info.path == "lattice-mgpcg":
             # The kernel with the largest share of the step (profiles/r01_mgpcg_final_kernel_stats.csv) is the
             # fused CG step dia_strip_kernel<M_APPLY, F_PUPD> (p = z + beta p, x += alpha p_old, Ap = A p, p.Ap);
             # it is timed alone on the operator this workload assembles (shared unit matrix + kappa_b scale).
@@ -229,7 +230,7 @@ def main():
             except Exception:
                 traffic = None
             del z, x, p_in, p_out, Ap, rhs, vals
-        elif solver.last_info.path == "ell-pcg":
+        elif roofline_ok and solver.last_info.path == "ell-pcg":
             W = plan.W
             vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
             x = torch.rand((n, Bp), dtype=torch.float64, device=dev)

@@ -30,7 +30,7 @@ for _ in range(200):
     loss = ((DifferentiableFESolver(mesh, kappa.abs())(f) - u_data) ** 2).mean()
     loss.backward()
     opt.step()
-print(f"[1D] recovered kappa = {float(kappa.detach().abs()):.4f} (true 2.0000), loss {float(loss):.2e}")
+print(f"[1D] recovered kappa = {float(kappa.detach().abs()):.4f} (true 2.0000), loss {float(loss.detach()):.2e}")
 
 # --- 2D: 256 kappa samples on a 512 x 512 mesh, forward + adjoint -----------------------------------
 mesh = FEMesh.rectangle(512, 512)

@@ -33,4 +33,4 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"config 5 shard: {N}x{N}, {B} samples, {STEPS} Adam steps in {dt:.2f} s = {STEPS / dt:.1f} steps/s "
       f"({STEPS * B / dt:.0f} differentiable solves/s); max |kappa - kappa_true| = "
-      f"{float((k.detach().abs() - k_true).abs().max()):.2e}, final loss {float(loss):.2e}")
+      f"{float((k.detach().abs() - k_true).abs().max()):.2e}, final loss {float(loss.detach()):.2e}")
