@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------
 struct CgScalars {  // each (Bp) doubles, in `work` after the vectors and partials
   double *rz, *pAp, *alpha, *beta, *bb, *tol2, *rr;
+  double* xx;             // |x|^2 of the current iterate (AMG path: attainable-accuracy floor), may be NULL
+  const double* maxdiag;  // per-sample (Bv entries) max diagonal entry, with xx
+  int Bv;
   int* active;    // (Bp)
   int* iters;     // (Bp)
   int* n_active;  // (1)
@@ -344,7 +347,7 @@ __device__ inline double sum_partials(const double* __restrict__ part, int nblk,
   return t;
 }
 
-enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3 };
+enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3, PH_XX = 4 };
 
 __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double* __restrict__ partA,
                                                          const double* __restrict__ partB, int nblk, int Bp,
@@ -370,7 +373,13 @@ __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double*
     if (S.active[b]) {
       S.iters[b] += 1;
       S.rr[b] = c;
-      if (c <= S.tol2[b]) {
+      double thr = S.tol2[b];
+      if (S.xx) {  // fp64 cannot bring |b - A x| below ~ u |A| |x|: stop at half of that level (see diffhe_hip.h)
+        const double fl = 0.5 * 1.1102230246251565e-16 * 2.0 * S.maxdiag[S.Bv == 1 ? 0 : b];
+        const double floor2 = fl * fl * S.xx[b];
+        if (floor2 > thr) thr = floor2;
+      }
+      if (c <= thr) {
         S.active[b] = 0;
         S.beta[b] = 0.0;
       } else {
@@ -381,6 +390,8 @@ __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double*
     } else {
       S.beta[b] = 0.0;
     }
+  } else if (phase == PH_XX) {  // a = x.x
+    S.xx[b] = a;
   } else {  // PH_RELRES: a = |b - A x|^2
     relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
   }
@@ -576,25 +587,49 @@ __global__ __launch_bounds__(256) void agg_prolong_add_kernel(const double* __re
 // x += alpha p ; r -= alpha Ap ; partial r.r
 __global__ __launch_bounds__(256) void amg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                           const double* __restrict__ alpha, double* __restrict__ x,
-                                                          double* __restrict__ r, double* __restrict__ part_rr, int n,
-                                                          int Bp) {
+                                                          double* __restrict__ r, double* __restrict__ part_rr,
+                                                          double* __restrict__ part_xx, int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
-  double s = 0.0;
+  double s = 0.0, sx = 0.0;
   if (ok) {
     const double a = alpha[nm.b];
     for (int i = nm.node0; i < n; i += nm.stride) {
       const i64 o = (i64)i * Bp + nm.b;
-      x[o] += a * p[o];
+      const double xi = x[o] + a * p[o];
+      x[o] = xi;
       const double ri = r[o] - a * Ap[o];
       r[o] = ri;
       s += ri * ri;
+      sx += xi * xi;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double t = block_sum_per_sample(s, Bp, lds);
-  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_rr[(i64)blockIdx.x * Bp + nm.b] = t;
+  const double tx = part_xx ? block_sum_per_sample(sx, Bp, lds) : 0.0;
+  if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) {
+    part_rr[(i64)blockIdx.x * Bp + nm.b] = t;
+    if (part_xx) part_xx[(i64)blockIdx.x * Bp + nm.b] = tx;
+  }
+}
+
+// Per-sample max of the ELL diagonal (slot 0), as the bit pattern of a non-negative double (atomicMax: deterministic)
+__global__ __launch_bounds__(256) void ell_maxdiag_kernel(const double* __restrict__ vals, int n, int Bv,
+                                                           unsigned long long* __restrict__ out) {
+  const NodeMap nm = node_map(Bv);
+  double m = 0.0;
+  if (nm.b < Bv)
+    for (int i = nm.node0; i < n; i += nm.stride) {
+      const double d = vals[(i64)i * Bv + nm.b];
+      m = d > m ? d : m;
+    }
+  const int LB = Bv < kWave ? Bv : kWave;
+  for (int off = LB; off < kWave; off <<= 1) {
+    const double o = __shfl_xor(m, off);
+    m = o > m ? o : m;
+  }
+  if ((int)(threadIdx.x & 63) < LB && nm.b < Bv) atomicMax(out + nm.b, (unsigned long long)__double_as_longlong(m));
 }
 
 // x = 0 ; r = b ; partial b.b
@@ -789,6 +824,9 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
   S.active = (int*)(sc + 7 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 8 * Bp);
+  S.xx = nullptr;  // plain `tol` stop on this path
+  S.maxdiag = nullptr;
+  S.Bv = Bv;
   const dim3 sgrid((Bp + 63) / 64);
 
   hipLaunchKernelGGL(cg_init_kernel, grid, dim3(256), 0, st, vals, b, x, r, z, p, partA, partB, n, Bp, Bv);
@@ -849,7 +887,7 @@ extern "C" long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* le
   if (amg_fill(H, levels, n_levels, 1, Bp)) return -1;
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = cg_blocks(H.lev[0].n, Bp);
-  return amg_carve(H, nullptr) + 3 * nb + 3 * nblk * Bp + 16LL * Bp + 64;
+  return amg_carve(H, nullptr) + 3 * nb + 4 * nblk * Bp + 16LL * Bp + 64;
 }
 
 extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x,
@@ -875,14 +913,24 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   double* partA = Ap + NB;
   double* partB = partA + (long long)nblk * Bp;
   double* partC = partB + (long long)nblk * Bp;
-  double* sc = partC + (long long)nblk * Bp;
+  double* partD = partC + (long long)nblk * Bp;
+  double* sc = partD + (long long)nblk * Bp;
   CgScalars S;
   S.rz = sc; S.pAp = sc + Bp; S.alpha = sc + 2 * Bp; S.beta = sc + 3 * Bp; S.bb = sc + 4 * Bp;
   S.tol2 = sc + 5 * Bp; S.rr = sc + 6 * Bp;
   S.active = (int*)(sc + 7 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 8 * Bp);
+  S.xx = sc + 9 * Bp;
+  S.maxdiag = sc + 10 * Bp;
+  S.Bv = Bv;
   const dim3 sgrid((Bp + 63) / 64);
+  rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));
+  if (rc) return rc;
+  rc = diffhe::check(hipMemsetAsync((void*)S.xx, 0, sizeof(double) * Bp, st));
+  if (rc) return rc;
+  hipLaunchKernelGGL(ell_maxdiag_kernel, diffhe::node_grid(n, Bv, 512), dim3(256), 0, st, L0.vals, n, Bv,
+                     (unsigned long long*)S.maxdiag);
 
   hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, p, partC, n, Bp);
   const double* z = amg_cycle(H, 0, r, partB, st);
@@ -897,7 +945,9 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, (const double*)partA,
                        (const double*)nullptr, nblk, Bp, tol, S, relres);
     hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
-                       (const double*)S.alpha, x, r, partC, n, Bp);
+                       (const double*)S.alpha, x, r, partC, partD, n, Bp);
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_XX, (const double*)partD,
+                       (const double*)nullptr, nblk, Bp, tol, S, relres);
     z = amg_cycle(H, 0, r, partB, st);
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, (const double*)partB, (const double*)partC,
                        nblk, Bp, tol, S, relres);

@@ -164,7 +164,9 @@ int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* 
 /* Batched CG preconditioned by one aggregation-multigrid cycle: V(2,2) Chebyshev-weighted Jacobi,
  * `gamma` coarse corrections per level (2 = W-cycle), coarse correction scaled by `scale`, n_coarse
  * sweeps on the last level.  Replaces torch.linalg.solve (solver.py:174) on general meshes.
- * Arguments as diffhe_ell_cg_solve; levels is a HOST array. */
+ * Arguments as diffhe_ell_cg_solve; levels is a HOST array.  The stop is floored like
+ * diffhe_lattice_pcg_solve's: sample b stops at |r| <= max(tol |b|, 0.5 u |A_b| |x_b|), with the running
+ * iterate x (this path starts from 0). */
 long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* levels, int n_levels, int Bp);
 int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x, int Bp,
                              double tol, int max_iter, int n_coarse, int gamma, double scale, double* work,
