@@ -106,6 +106,11 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    # dominant kernel (fused CG step) timed with HIP events INSIDE the solver loop, over the timed region only
+    import ctypes
+    prof_ms, prof_n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+    if rank == 0:
+        _hip.lib().diffhe_lattice_pcg_profile(1, None, None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, u = step()
@@ -113,6 +118,8 @@ def main():
             dist.all_reduce(loss)       # the only collective: scalar loss (per-sample kappa)
     sync_all()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        _hip.lib().diffhe_lattice_pcg_profile(0, ctypes.byref(prof_ms), ctypes.byref(prof_n))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,10 +250,19 @@ def main():
             kname = "cg_spmv_kernel"
             del vals, x, y, part
         if roofline_ok:
-            achieved = alg_bytes / dur / 1e9
+            # `achieved` = the kernel's average duration INSIDE the solver, HIP events over the timed region (cold
+            # caches between the V-cycle and the residual update; this is the figure the rocprofv3 kernel stats of
+            # the same command show); the back-to-back launches above are reported next to it as `isolated_*`.
+            iso = alg_bytes / dur / 1e9
+            in_loop = prof_n.value > 0 and solver.last_info.path == "lattice-mgpcg"
+            dur_used = (prof_ms.value * 1e-3 / prof_n.value) if in_loop else dur
+            achieved = alg_bytes / dur_used / 1e9
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur * 1e3, 4),
+                    "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur_used * 1e3, 4),
+                    "launches_timed": int(prof_n.value) if in_loop else None,
+                    "isolated_launch_ms": round(dur * 1e3, 4), "isolated_achieved": round(iso, 1),
+                    "isolated_frac": round(iso / HBM_PEAK_GBS, 4),
                     "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None, "other_kernels": other}
 
         # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------

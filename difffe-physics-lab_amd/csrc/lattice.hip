@@ -1110,6 +1110,34 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
 
 }  // namespace
 
+// Opt-in timing of the dominant kernel INSIDE the solver loop (bench.py's roofline entry): HIP events around every
+// fused CG-step launch, read after the per-iteration stream synchronisation the loop performs anyway.
+namespace {
+struct StepProfile {
+  bool on = false;
+  bool have = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double ms = 0.0;
+  long long launches = 0;
+};
+thread_local StepProfile g_prof;
+}  // namespace
+
+extern "C" int diffhe_lattice_pcg_profile(int enable, double* total_ms, long long* launches) {
+  if (total_ms) *total_ms = g_prof.ms;
+  if (launches) *launches = g_prof.launches;
+  if (enable >= 0) {
+    if (enable && !g_prof.e0) {
+      if (hipEventCreate(&g_prof.e0) != hipSuccess || hipEventCreate(&g_prof.e1) != hipSuccess) return DIFFHE_E_LAUNCH;
+    }
+    g_prof.on = enable != 0;
+    g_prof.ms = 0.0;
+    g_prof.launches = 0;
+    g_prof.have = false;
+  }
+  return DIFFHE_OK;
+}
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -1247,6 +1275,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   };
   auto apply_step = [&](int first) {
     if (fused) {
+      if (g_prof.on && !first) {  // the first step of a solve (p = z, nothing pending) moves fewer bytes: not timed
+        (void)hipEventRecord(g_prof.e0, st);
+        g_prof.have = true;
+      }
       Extra ex{};
       ex.a0 = z; ex.p_in = p; ex.p_out = p2; ex.x = x; ex.alpha = S.alpha; ex.beta = S.beta; ex.first = first;
       if (f32)
@@ -1257,6 +1289,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
                                                              (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
       double* t = p; p = p2; p2 = t;
       nba = g0.ncb * g0.nrc;
+      if (g_prof.on && !first) (void)hipEventRecord(g_prof.e1, st);
     } else {
       if (f32) LAUNCH(pcg_update_p_kernel<float>, n, (const float*)z, (const double*)S.beta, p, first, n, Bp);
       else LAUNCH(pcg_update_p_kernel<double>, n, (const double*)z, (const double*)S.beta, p, first, n, Bp);
@@ -1303,6 +1336,14 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     rc = diffhe::check(hipStreamSynchronize(st));
     if (rc) return rc;
     n_active = status_host[2];
+    if (g_prof.on && g_prof.have) {  // the stream is idle here: both events have completed
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, g_prof.e0, g_prof.e1) == hipSuccess) {
+        g_prof.ms += ms;
+        g_prof.launches += 1;
+      }
+      g_prof.have = false;
+    }
     if (n_active == 0) break;
   }
   if (fused && it > 0) {

@@ -221,6 +221,11 @@ int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv
                              const double* b, double* x, int Bp, double tol, int max_iter, int nu, int n_coarse,
                              const double* omegas_host, int precond_fp32, double* work, double* relres,
                              int* iters, int* status_host, void* stream);
+/* Opt-in timing of the fused CG-step kernel (the dominant one) inside diffhe_lattice_pcg_solve's own loop, for
+ * bench.py's roofline entry: enable = 1 creates two HIP events (per calling thread, the only hidden state in the
+ * library, and only in this mode) and resets the counters, 0 stops, < 0 only reads.  The events bracket each launch
+ * on the solve's stream and are read after the loop's per-iteration synchronisation.  Returns the totals so far. */
+int diffhe_lattice_pcg_profile(int enable, double* total_ms, long long* launches);
 /* Single kernels of that loop, exposed for timing/tests: y = A x (+ x.y block partials in
  * `part`, diffhe_lattice_blocks(n, Bp) * Bp doubles) and one damped-Jacobi sweep
  * xout = xin + omega (rhs - A xin)/D  (xin NULL = 0). */
