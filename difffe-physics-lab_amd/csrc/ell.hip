@@ -289,14 +289,15 @@ __global__ __launch_bounds__(256) void cg_update_kernel(const double* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void cg_update_p_kernel(const double* __restrict__ z, const double* __restrict__ beta,
+template <typename TZ>
+__global__ __launch_bounds__(256) void cg_update_p_kernel(const TZ* __restrict__ z, const double* __restrict__ beta,
                                                            double* __restrict__ p, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
   const double be = beta[nm.b];
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    p[o] = z[o] + be * p[o];
+    p[o] = (double)z[o] + be * p[o];
   }
 }
 
@@ -505,12 +506,14 @@ __global__ __launch_bounds__(256) void ell_galerkin_kernel(const double* __restr
     }
 }
 
-// weighted Jacobi: xout = xin + omega (b - A xin) / D (xin == NULL: from zero); optional partial of b.xout
-__global__ __launch_bounds__(256) void ell_jacobi_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
-                                                          const double* __restrict__ bvec,
-                                                          const double* __restrict__ xin, double* __restrict__ xout,
-                                                          double omega, double* __restrict__ part, int n, int W, int Bp,
-                                                          int Bv) {
+// weighted Jacobi: xout = xin + omega (b - A xin) / D (xin == NULL: from zero); optional partial of b.xout.
+// TV = storage type of the cycle's vectors, TM = storage type of the matrix values (fp32 copies inside a
+// single-precision preconditioner); arithmetic is fp64 in registers.
+template <typename TV, typename TM>
+__global__ __launch_bounds__(256) void ell_jacobi_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
+                                                          const TV* __restrict__ bvec, const TV* __restrict__ xin,
+                                                          TV* __restrict__ xout, double omega,
+                                                          double* __restrict__ part, int n, int W, int Bp, int Bv) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
@@ -519,20 +522,20 @@ __global__ __launch_bounds__(256) void ell_jacobi_kernel(const double* __restric
   if (ok)
     for (int i = nm.node0; i < n; i += nm.stride) {
       const i64 o = (i64)i * Bp + nm.b;
-      const double d = vals[(i64)i * Bv + vb];
-      const double bi = bvec[o];
+      const double d = (double)vals[(i64)i * Bv + vb];
+      const double bi = (double)bvec[o];
       double xo;
       if (xin) {
         double acc = bi;
         for (int k = 0; k < W; ++k) {
           const i64 ent = (i64)k * n + i;
-          acc -= vals[ent * Bv + vb] * xin[(i64)cols[ent] * Bp + nm.b];
+          acc -= (double)vals[ent * Bv + vb] * (double)xin[(i64)cols[ent] * Bp + nm.b];
         }
-        xo = xin[o] + omega * acc / d;
+        xo = (double)xin[o] + omega * acc / d;
       } else {
         xo = omega * bi / d;
       }
-      xout[o] = xo;
+      xout[o] = (TV)xo;
       s += bi * xo;
     }
   if (part) {
@@ -542,53 +545,55 @@ __global__ __launch_bounds__(256) void ell_jacobi_kernel(const double* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void ell_residual_out_kernel(const double* __restrict__ vals,
-                                                                const int* __restrict__ cols,
-                                                                const double* __restrict__ bvec,
-                                                                const double* __restrict__ x, double* __restrict__ r,
-                                                                int n, int W, int Bp, int Bv) {
+template <typename TV, typename TM>
+__global__ __launch_bounds__(256) void ell_residual_out_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
+                                                                const TV* __restrict__ bvec, const TV* __restrict__ x,
+                                                                TV* __restrict__ r, int n, int W, int Bp, int Bv) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
   const int vb = Bv == 1 ? 0 : nm.b;
   for (int i = nm.node0; i < n; i += nm.stride) {
-    double acc = bvec[(i64)i * Bp + nm.b];
+    double acc = (double)bvec[(i64)i * Bp + nm.b];
     for (int k = 0; k < W; ++k) {
       const i64 ent = (i64)k * n + i;
-      acc -= vals[ent * Bv + vb] * x[(i64)cols[ent] * Bp + nm.b];
+      acc -= (double)vals[ent * Bv + vb] * (double)x[(i64)cols[ent] * Bp + nm.b];
     }
-    r[(i64)i * Bp + nm.b] = acc;
+    r[(i64)i * Bp + nm.b] = (TV)acc;
   }
 }
 
 // rc[I] = sum of r over the members of aggregate I (fixed order)
-__global__ __launch_bounds__(256) void agg_restrict_kernel(const double* __restrict__ r, const int* __restrict__ agg_ptr,
-                                                            const int* __restrict__ members, double* __restrict__ rc,
+template <typename TV>
+__global__ __launch_bounds__(256) void agg_restrict_kernel(const TV* __restrict__ r, const int* __restrict__ agg_ptr,
+                                                            const int* __restrict__ members, TV* __restrict__ rc,
                                                             int nc, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
   for (int I = nm.node0; I < nc; I += nm.stride) {
     double s = 0.0;
-    for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s += r[(i64)members[c] * Bp + nm.b];
-    rc[(i64)I * Bp + nm.b] = s;
+    for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s += (double)r[(i64)members[c] * Bp + nm.b];
+    rc[(i64)I * Bp + nm.b] = (TV)s;
   }
 }
 
 // x[i] += scale * e[agg[i]]
-__global__ __launch_bounds__(256) void agg_prolong_add_kernel(const double* __restrict__ e, const int* __restrict__ agg,
-                                                               double* __restrict__ x, double scale, int n, int Bp) {
+template <typename TV>
+__global__ __launch_bounds__(256) void agg_prolong_add_kernel(const TV* __restrict__ e, const int* __restrict__ agg,
+                                                               TV* __restrict__ x, double scale, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const int I = agg[i];
-    if (I >= 0) x[(i64)i * Bp + nm.b] += scale * e[(i64)I * Bp + nm.b];
+    if (I >= 0) x[(i64)i * Bp + nm.b] = (TV)((double)x[(i64)i * Bp + nm.b] + scale * (double)e[(i64)I * Bp + nm.b]);
   }
 }
 
 // x += alpha p ; r -= alpha Ap ; partial r.r
 __global__ __launch_bounds__(256) void amg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                           const double* __restrict__ alpha, double* __restrict__ x,
-                                                          double* __restrict__ r, double* __restrict__ part_rr,
-                                                          double* __restrict__ part_xx, int n, int Bp) {
+                                                          double* __restrict__ r, float* __restrict__ r32,
+                                                          double* __restrict__ part_rr, double* __restrict__ part_xx,
+                                                          int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
@@ -601,6 +606,7 @@ __global__ __launch_bounds__(256) void amg_update_kernel(const double* __restric
       x[o] = xi;
       const double ri = r[o] - a * Ap[o];
       r[o] = ri;
+      if (r32) r32[o] = (float)ri;
       s += ri * ri;
       sx += xi * xi;
     }
@@ -634,8 +640,9 @@ __global__ __launch_bounds__(256) void ell_maxdiag_kernel(const double* __restri
 
 // x = 0 ; r = b ; partial b.b
 __global__ __launch_bounds__(256) void amg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
-                                                        double* __restrict__ r, double* __restrict__ p,
-                                                        double* __restrict__ part_bb, int n, int Bp) {
+                                                        double* __restrict__ r, float* __restrict__ r32,
+                                                        double* __restrict__ p, double* __restrict__ part_bb, int n,
+                                                        int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
@@ -645,6 +652,7 @@ __global__ __launch_bounds__(256) void amg_init_kernel(const double* __restrict_
       const i64 o = (i64)i * Bp + nm.b;
       const double bi = bvec[o];
       x[o] = 0.0; r[o] = bi; p[o] = 0.0;
+      if (r32) r32[o] = (float)bi;
       s += bi * bi;
     }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -658,7 +666,7 @@ struct AmgHier {
   diffhe_amg_level lev[kAmgMaxLevels];
   int nl, Bv, Bp, n_coarse, gamma;
   double w0, w1, scale;
-  double *xa[kAmgMaxLevels], *xb[kAmgMaxLevels], *res[kAmgMaxLevels], *rhs[kAmgMaxLevels];
+  void *xa[kAmgMaxLevels], *xb[kAmgMaxLevels], *res[kAmgMaxLevels], *rhs[kAmgMaxLevels];  // TV vectors
 };
 
 #define ALAUNCH(kernel, n_, ...) \
@@ -667,39 +675,52 @@ struct AmgHier {
 // x ~= A_l^{-1} rhs from a zero guess: V(2,2) weighted Jacobi, `gamma` coarse corrections per level
 // (gamma = 2: W-cycle -- affordable because aggregation coarsens by ~10x -- compensates the weak
 // piecewise-constant interpolation).  Returns the buffer holding the result.
-double* amg_cycle(const AmgHier& H, int l, const double* rhs, double* rz_part, hipStream_t st) {
+template <typename TV>
+TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream_t st) {
   const diffhe_amg_level& L = H.lev[l];
-  double* a = H.xa[l];
-  double* b2 = H.xb[l];
+  TV* a = (TV*)H.xa[l];
+  TV* b2 = (TV*)H.xb[l];
   const bool last = (l == H.nl - 1);
   const int pre = last ? H.n_coarse : 2;
+  // per-sample matrices inside the fp32 cycle read the fp32 copy of the values
+  const bool m32 = sizeof(TV) == 4 && H.Bv != 1 && L.vals32 != nullptr;
+#define AMG_JACOBI(xin_, xout_, w_, part_)                                                                          \
+  do {                                                                                                              \
+    if (m32)                                                                                                        \
+      ALAUNCH((ell_jacobi_kernel<TV, float>), L.n, L.vals32, L.cols, rhs, xin_, xout_, w_, part_, L.n, L.W, H.Bp, H.Bv); \
+    else                                                                                                            \
+      ALAUNCH((ell_jacobi_kernel<TV, double>), L.n, L.vals, L.cols, rhs, xin_, xout_, w_, part_, L.n, L.W, H.Bp, H.Bv);  \
+  } while (0)
   for (int s = 0; s < pre; ++s) {
     const double w = (s & 1) ? H.w1 : H.w0;
     const bool fin = last && s == pre - 1;
     if (s == 0) {
-      ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)nullptr, a, w, fin ? rz_part : (double*)nullptr,
-              L.n, L.W, H.Bp, H.Bv);
+      AMG_JACOBI((const TV*)nullptr, a, w, fin ? rz_part : (double*)nullptr);
     } else {
-      ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, b2, w, fin ? rz_part : (double*)nullptr, L.n,
-              L.W, H.Bp, H.Bv);
-      double* t = a; a = b2; b2 = t;
+      AMG_JACOBI((const TV*)a, b2, w, fin ? rz_part : (double*)nullptr);
+      TV* t = a; a = b2; b2 = t;
     }
   }
   if (last) return a;
   const diffhe_amg_level& C = H.lev[l + 1];
   const int cycles = (l + 1 == H.nl - 1) ? 1 : H.gamma;  // the last level is "solved": one visit is enough
   for (int g = 0; g < cycles; ++g) {
-    ALAUNCH(ell_residual_out_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, H.res[l], L.n, L.W, H.Bp, H.Bv);
-    ALAUNCH(agg_restrict_kernel, C.n, (const double*)H.res[l], L.agg_ptr, L.agg_members, H.rhs[l + 1], C.n, H.Bp);
-    const double* ec = amg_cycle(H, l + 1, H.rhs[l + 1], nullptr, st);
-    ALAUNCH(agg_prolong_add_kernel, L.n, ec, L.agg, a, H.scale, L.n, H.Bp);
+    if (m32)
+      ALAUNCH((ell_residual_out_kernel<TV, float>), L.n, L.vals32, L.cols, rhs, (const TV*)a, (TV*)H.res[l], L.n, L.W,
+              H.Bp, H.Bv);
+    else
+      ALAUNCH((ell_residual_out_kernel<TV, double>), L.n, L.vals, L.cols, rhs, (const TV*)a, (TV*)H.res[l], L.n, L.W,
+              H.Bp, H.Bv);
+    ALAUNCH(agg_restrict_kernel<TV>, C.n, (const TV*)H.res[l], L.agg_ptr, L.agg_members, (TV*)H.rhs[l + 1], C.n, H.Bp);
+    const TV* ec = amg_cycle<TV>(H, l + 1, (const TV*)H.rhs[l + 1], nullptr, st);
+    ALAUNCH(agg_prolong_add_kernel<TV>, L.n, ec, L.agg, a, H.scale, L.n, H.Bp);
   }
   for (int s = 0; s < 2; ++s) {
     const double w = (s & 1) ? H.w0 : H.w1;  // reverse order: symmetric cycle
-    ALAUNCH(ell_jacobi_kernel, L.n, L.vals, L.cols, rhs, (const double*)a, b2, w,
-            (l == 0 && s == 1) ? rz_part : (double*)nullptr, L.n, L.W, H.Bp, H.Bv);
-    double* t = a; a = b2; b2 = t;
+    AMG_JACOBI((const TV*)a, b2, w, (l == 0 && s == 1) ? rz_part : (double*)nullptr);
+    TV* t = a; a = b2; b2 = t;
   }
+#undef AMG_JACOBI
   return a;
 }
 
@@ -711,7 +732,7 @@ long long amg_carve(AmgHier& H, double* work) {
     H.xa[l] = take(nb);
     H.xb[l] = take(nb);
     H.res[l] = take(nb);
-    H.rhs[l] = l > 0 ? take(nb) : nullptr;
+    H.rhs[l] = take(nb);  // level 0: the fp32 copy of the CG residual (fp32 cycle)
   }
   return off;
 }
@@ -842,7 +863,7 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
     hipLaunchKernelGGL(cg_update_kernel, grid, dim3(256), 0, st, vals, p, Ap, S.alpha, x, r, z, partB, partC, n, Bp,
                        Bv);
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, partB, partC, nblk, Bp, tol, S, relres);
-    hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, S.beta, p, n, Bp);
+    hipLaunchKernelGGL(cg_update_p_kernel<double>, grid, dim3(256), 0, st, (const double*)z, (const double*)S.beta, p, n, Bp);
     ++it;
     if (it % check_every == 0 || it == max_iter) {
       rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -892,7 +913,7 @@ extern "C" long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* le
 
 extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x,
                                         int Bp, double tol, int max_iter, int n_coarse, int gamma, double scale,
-                                        double* work, double* relres, int* iters, int* status_host, void* stream) {
+                                        int precond_fp32, double* work, double* relres, int* iters, int* status_host, void* stream) {
   if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0 || n_coarse < 1 || gamma < 1)
     return DIFFHE_E_BADARG;
   AmgHier H;
@@ -921,22 +942,37 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   S.active = (int*)(sc + 7 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 8 * Bp);
-  S.xx = sc + 9 * Bp;
+  S.xx = (precond_fp32 & 16) ? nullptr : sc + 9 * Bp;  // bit 4: stop on `tol` alone
   S.maxdiag = sc + 10 * Bp;
   S.Bv = Bv;
   const dim3 sgrid((Bp + 63) / 64);
   rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));
   if (rc) return rc;
-  rc = diffhe::check(hipMemsetAsync((void*)S.xx, 0, sizeof(double) * Bp, st));
-  if (rc) return rc;
+  if (S.xx) {
+    rc = diffhe::check(hipMemsetAsync((void*)S.xx, 0, sizeof(double) * Bp, st));
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(ell_maxdiag_kernel, diffhe::node_grid(n, Bv, 512), dim3(256), 0, st, L0.vals, n, Bv,
                      (unsigned long long*)S.maxdiag);
 
-  hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, p, partC, n, Bp);
-  const double* z = amg_cycle(H, 0, r, partB, st);
+  // fp32 cycle: the preconditioner STORES its vectors (and, for per-sample matrices, reads copies of the values) in
+  // fp32; the CG, its residual, the iterate and every dot product stay fp64 (as in diffhe_lattice_pcg_solve)
+  const bool f32 = (precond_fp32 & 1) != 0;
+  float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
+  const void* z = nullptr;
+  auto precondition = [&]() {
+    if (f32) z = amg_cycle<float>(H, 0, (const float*)r32, partB, st);
+    else z = amg_cycle<double>(H, 0, (const double*)r, partB, st);
+  };
+  auto update_p = [&]() {
+    if (f32) hipLaunchKernelGGL(cg_update_p_kernel<float>, grid, dim3(256), 0, st, (const float*)z, (const double*)S.beta, p, n, Bp);
+    else hipLaunchKernelGGL(cg_update_p_kernel<double>, grid, dim3(256), 0, st, (const double*)z, (const double*)S.beta, p, n, Bp);
+  };
+  hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, r32, p, partC, n, Bp);
+  precondition();
   hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, (const double*)partB, (const double*)partC,
                      nblk, Bp, tol, S, relres);
-  hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, (const double*)S.beta, p, n, Bp);  // beta = 0: p = z
+  update_p();  // beta = 0: p = z
   rc = diffhe::check_launch();
   if (rc) return rc;
   int it = 0, n_active = -1;
@@ -945,13 +981,14 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, (const double*)partA,
                        (const double*)nullptr, nblk, Bp, tol, S, relres);
     hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
-                       (const double*)S.alpha, x, r, partC, partD, n, Bp);
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_XX, (const double*)partD,
-                       (const double*)nullptr, nblk, Bp, tol, S, relres);
-    z = amg_cycle(H, 0, r, partB, st);
+                       (const double*)S.alpha, x, r, r32, partC, S.xx ? partD : (double*)nullptr, n, Bp);
+    if (S.xx)
+      hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_XX, (const double*)partD,
+                         (const double*)nullptr, nblk, Bp, tol, S, relres);
+    precondition();
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, (const double*)partB, (const double*)partC,
                        nblk, Bp, tol, S, relres);
-    hipLaunchKernelGGL(cg_update_p_kernel, grid, dim3(256), 0, st, z, (const double*)S.beta, p, n, Bp);
+    update_p();
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
     if (rc) return rc;

@@ -25,7 +25,8 @@ _LV = C.POINTER(MgLevel)
 
 class AmgLevel(C.Structure):
     """struct diffhe_amg_level (include/diffhe_hip.h)."""
-    _fields_ = [("n", _I), ("W", _I), ("vals", _P), ("cols", _P), ("agg", _P), ("agg_ptr", _P), ("agg_members", _P)]
+    _fields_ = [("n", _I), ("W", _I), ("vals", _P), ("cols", _P), ("agg", _P), ("agg_ptr", _P), ("agg_members", _P),
+                ("vals32", _P)]
 
 
 _AV = C.POINTER(AmgLevel)
@@ -46,7 +47,7 @@ SIGNATURES = {
     "diffhe_ell_cg_solve": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
     "diffhe_ell_galerkin": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "diffhe_ell_amg_workspace_doubles": (_L, [_AV, _I, _I]),
-    "diffhe_ell_amg_pcg_solve": (_I, [_AV, _I, _I, _P, _P, _I, _D, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "diffhe_ell_amg_pcg_solve": (_I, [_AV, _I, _I, _P, _P, _I, _D, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P]),
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pcg_workspace_doubles": (_L, [_LV, _I, _I]),
     "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P, _P,
@@ -84,7 +85,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.diffhe_abi_version() != 1:
+        if handle.diffhe_abi_version() != 2:
             raise HipExtensionError("libdiffhe_hip.so ABI version mismatch")
         _lib = handle
     return _lib

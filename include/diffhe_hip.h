@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 1
+#define DIFFHE_ABI_VERSION 2
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -156,6 +156,7 @@ typedef struct diffhe_amg_level {
   const int* agg;          /* (n) node -> node of the NEXT level, -1 = none (Dirichlet); NULL on the last level */
   const int* agg_ptr;      /* (n_next + 1) CSR of the members of each next-level node; NULL on the last level */
   const int* agg_members;  /* node ids, grouped by aggregate */
+  const float* vals32;     /* optional fp32 copy of vals, read by the fp32 cycle when Bv == Bp (may be NULL) */
 } diffhe_amg_level;
 
 /* vals_coarse[(k*n_coarse + I)*Bv + b] = sum of vals_fine[contrib[c]*Bv + b], c in ent_ptr[k*n_coarse+I] .. */
@@ -164,12 +165,15 @@ int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* 
 /* Batched CG preconditioned by one aggregation-multigrid cycle: V(2,2) Chebyshev-weighted Jacobi,
  * `gamma` coarse corrections per level (2 = W-cycle), coarse correction scaled by `scale`, n_coarse
  * sweeps on the last level.  Replaces torch.linalg.solve (solver.py:174) on general meshes.
+ * precond_fp32 bit 0: the cycle stores its vectors in fp32 (arithmetic fp64 in registers) and reads levels[].vals32
+ * where given; the CG vectors, residuals and dot products stay fp64.  Bit 4: stop on `tol` alone (no floor).
  * Arguments as diffhe_ell_cg_solve; levels is a HOST array.  The stop is floored like
  * diffhe_lattice_pcg_solve's: sample b stops at |r| <= max(tol |b|, 0.5 u |A_b| |x_b|), with the running
  * iterate x (this path starts from 0). */
 long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* levels, int n_levels, int Bp);
 int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x, int Bp,
-                             double tol, int max_iter, int n_coarse, int gamma, double scale, double* work,
+                             double tol, int max_iter, int n_coarse, int gamma, double scale, int precond_fp32,
+                             double* work,
                              double* relres, int* iters, int* status_host, void* stream);
 
 /* One application of the batched operator, y = A x, with the per-sample dots x.y left as

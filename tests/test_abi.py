@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(handle, name), name
     L = _hip.lib()
-    assert L.diffhe_abi_version() == 1
+    assert L.diffhe_abi_version() == 2
     assert L.diffhe_status_string(0) == b"ok"
     assert b"batch" in L.diffhe_status_string(-4)
     assert L.diffhe_cg_workspace_doubles(1000, 64) > 4 * 1000 * 64
