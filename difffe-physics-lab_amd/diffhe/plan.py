@@ -270,10 +270,15 @@ class SolvePlan:
         self.levels = []
         lat = detect_lattice(elements, self.n) if self.dim == 2 else None
         self.is_lattice = lat is not None
+        self.n_bc_interior = 0
         if self.is_lattice:
             nx, ny = lat
             nodes2d = nodes.reshape(ny + 1, nx + 1, 2)
             bc2d = is_bc.reshape(ny + 1, nx + 1)
+            # Dirichlet nodes strictly inside the lattice: the geometric hierarchy only keeps those that fall on
+            # coarse nodes, so many of them (pinned regions, holes) weaken the V-cycle -- the solver then routes
+            # the mesh to the aggregation-multigrid path, whose Galerkin operators see every one of them
+            self.n_bc_interior = int(bc2d[1:-1, 1:-1].sum())
             while len(self.levels) < 16:
                 self.levels.append(LatticeLevel(nodes2d, bc2d, device, with_load_matrix=not self.levels))
                 step = coarsening_step(nodes2d)

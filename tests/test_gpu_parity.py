@@ -833,3 +833,33 @@ def test_2d_second_order_convergence():
         errs.append(float((u.cpu() - exact).abs().max()))
     for a, b in zip(errs, errs[1:]):
         assert 3.3 < a / b < 4.7
+
+
+@pytest.mark.gpu
+def test_lattice_with_many_interior_dirichlet_nodes():
+    """Pinned interior nodes: a few stay on the geometric-multigrid path; 5 % of the nodes (which the coarse
+    lattices cannot represent) route the mesh to the aggregation-multigrid path, forward AND adjoint."""
+    for frac, path in ((0.001, "lattice-mgpcg"), (0.05, "ell-amgpcg")):
+        rng = np.random.default_rng(9)
+        base = FEMesh.rectangle(96, 80, (0.0, 1.2), (0.0, 1.0), 0.0)
+        d = dict(base.dirichlet_nodes)
+        for k in rng.choice(base.n_nodes, int(frac * base.n_nodes), replace=False):
+            d[int(k)] = float(rng.uniform(-1, 1))
+        mesh = FEMesh(nodes=base.nodes, elements=base.elements, dirichlet_nodes=d)
+        nodes, el, bn, bv = arrays(mesh)
+        B = 5
+        kap = rng.uniform(0.5, 2.0, B)
+        f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+        kt = torch.from_numpy(kap).requires_grad_(True)
+        ft = torch.from_numpy(f).requires_grad_(True)
+        solver = DifferentiableFESolver(mesh, kt)
+        u = solver(ft)
+        (u ** 2).sum().backward()
+        info = solver.last_info
+        assert info.path == path and info.not_converged == 0
+        assert info.adj_iterations <= 3 * info.iterations + 10      # the adjoint uses the same preconditioner
+        for b in (0, B - 1):
+            uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
+            assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+            assert abs(float(kt.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
+            assert rel_err(ft.grad[b].numpy(), dfo) < RTOL_GRAD
