@@ -225,7 +225,7 @@ def solve(nodes, elements, bc_nodes, bc_vals, kappa, f, sparse=None):
 # Adjoint (what autograd computes through solver.py:89-96,139-145,169-181)
 # ---------------------------------------------------------------------------
 
-def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sparse=None):
+def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sparse=None, with_cond=False):
     """Forward solve, then the adjoint of it for the cotangent `gbar = gbar_fn(u)`.
 
     lambda_free = K_free^{-T} gbar_free, lambda_bc = 0   (LinalgSolveExBackward of solver.py:174)
@@ -233,7 +233,9 @@ def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sp
                   with the full u so the lifting term of solver.py:169 is included)
     dL/df       = M^T lambda, M the load map of solver.py:95-96 (1D) / 143-145 (2D).
     Returns (u, dL/dkappa per element (m,), dL/df (n,)); sum the per-element
-    vector for a scalar kappa.
+    vector for a scalar kappa.  with_cond=True appends sum_{p,q} |lambda_p| |k0_e[p,q]| |u_q| per element: the
+    magnitude of the terms each dL/dkappa_e is made of (when u is nearly constant over an element they cancel, and
+    the gradient is only defined to u * that magnitude in fp64 -- used by tools/stress.py to judge gradients).
     """
     nodes = np.asarray(nodes, dtype=np.float64)
     elements = np.asarray(elements, dtype=np.int64)
@@ -262,6 +264,8 @@ def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sp
         s = (lam_e[:, 0] + lam_e[:, 1] + lam_e[:, 2]) * (w / 9.0)
         for p in range(3):
             np.add.at(df, elements[:, p], s)
+    if with_cond:
+        return u, dkappa, df, np.einsum("ep,epq,eq->e", np.abs(lam_e), np.abs(k0), np.abs(u_e))
     return u, dkappa, df
 
 
