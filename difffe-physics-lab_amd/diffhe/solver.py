@@ -510,7 +510,19 @@ def _solve_backward(ctx, gbar, need_k, need_f):
 _SOLVERS: "weakref.WeakValueDictionary[int, DifferentiableFESolver]" = weakref.WeakValueDictionary()
 _STATES: Dict[int, object] = {}
 _TOKENS = itertools.count(1)
-_MAX_PENDING_STATES = 4     # forward calls whose backward never ran (e.g. dropped graphs)
+_MAX_PENDING_STATES = 64    # safety valve only: states normally live exactly as long as their autograd graph
+
+
+class _StateGuard:
+    """Owned by the autograd context of one differentiated solve: when the graph is freed (backward without
+    retain_graph, or the output tensor dropped) the saved adjoint state goes with it -- the lifetime autograd gives
+    its own saved tensors, so `backward(retain_graph=True)`, repeated backward passes and gradcheck work."""
+
+    def __init__(self, token: int):
+        self.token = token
+
+    def __del__(self):
+        _STATES.pop(self.token, None)
 
 
 @torch.library.custom_op("diffhe::fe_solve", mutates_args=())
@@ -543,10 +555,10 @@ def _fe_solve_fake(kappa, f, handle, save):
 def fe_solve_backward(gbar: torch.Tensor, token: torch.Tensor, need_k: bool, need_f: bool,
                       kappa_like: torch.Tensor, f_like: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dL/dkappa, dL/df) for the forward call named by `token`; unused gradients come back empty."""
-    state = _STATES.pop(int(token), None)
+    state = _STATES.get(int(token))
     if state is None:
-        raise RuntimeError("diffhe: adjoint state of this solve is gone (backward ran twice, or more than "
-                           f"{_MAX_PENDING_STATES} un-differentiated solves are pending)")
+        raise RuntimeError("diffhe: adjoint state of this solve is gone (its autograd graph was freed, or more than "
+                           f"{_MAX_PENDING_STATES} differentiated solves are alive at once)")
     gk, gf = _solve_backward(state, gbar, need_k, need_f)
     return (gk if gk is not None else kappa_like.new_empty(0), gf if gf is not None else f_like.new_empty(0))
 
@@ -560,6 +572,8 @@ def _fe_solve_backward_fake(gbar, token, need_k, need_f, kappa_like, f_like):
 def _fe_setup_context(ctx, inputs, output):
     kappa, f, _, _ = inputs
     ctx.save_for_backward(output[1], kappa, f)
+    if not isinstance(output[1], torch._subclasses.FakeTensor):
+        ctx.state_guard = _StateGuard(int(output[1]))       # frees the adjoint state together with the graph
 
 
 def _fe_backward(ctx, grad_u, _grad_token):

@@ -570,22 +570,43 @@ def test_empty_and_degenerate_inputs():
 
 
 def test_custom_op_state_lifecycle():
-    """Adjoint state is held only between forward and backward of a differentiated call."""
+    """The adjoint state lives exactly as long as the autograd graph of its solve: nothing is saved without grad,
+    a plain backward frees it, retain_graph keeps it for further backward passes (the reference, being pure
+    autograd, supports that), dropped graphs do not leak, and gradcheck (many backward passes) works."""
+    import gc
     from diffhe import solver as S
     mesh = FEMesh.rectangle(8, 8)
     k = torch.tensor(1.3, dtype=T64, requires_grad=True)
     f = torch.ones(mesh.n_nodes, dtype=T64)
+    gc.collect()
     S._STATES.clear()
     with torch.no_grad():
         DifferentiableFESolver(mesh, k)(f)
     assert len(S._STATES) == 0                                  # nothing saved without grad
     u = DifferentiableFESolver(mesh, k)(f)
     assert len(S._STATES) == 1
-    u.sum().backward()
-    assert len(S._STATES) == 0 and k.grad is not None           # consumed by the adjoint
-    for _ in range(3 * S._MAX_PENDING_STATES):                  # graphs that are dropped do not leak
+    L = (u ** 2).sum()
+    L.backward(retain_graph=True)
+    g1 = k.grad.clone()
+    assert len(S._STATES) == 1                                  # graph retained: state kept
+    L.backward()
+    assert torch.allclose(k.grad, 2 * g1)                       # second pass accumulated the same gradient
+    del u, L
+    gc.collect()
+    assert len(S._STATES) == 0                                  # freed with the graph
+    for _ in range(10):                                         # graphs that are dropped do not leak
         DifferentiableFESolver(mesh, k)(f)
-    assert len(S._STATES) <= S._MAX_PENDING_STATES
+    gc.collect()
+    assert len(S._STATES) == 0
+    m = FEMesh.rectangle(4, 3, bc_value=0.2)
+    kk = torch.tensor([0.8, 1.4], dtype=T64, requires_grad=True)
+    ff = (1 + 0.1 * torch.arange(2 * m.n_nodes, dtype=T64).reshape(2, -1) / m.n_nodes).requires_grad_(True)
+    s = DifferentiableFESolver(m, kk)
+
+    def fn(kv, fv):
+        s._kappa = kv
+        return s(fv)
+    assert torch.autograd.gradcheck(fn, (kk, ff), eps=1e-6, atol=1e-6, rtol=1e-4, nondet_tol=1e-10)
 
 
 @pytest.mark.parametrize("nx,ny", [(100, 37), (250, 250), (96, 72)])
