@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------
 struct CgScalars {  // each (Bp) doubles, in `work` after the vectors and partials
   double *rz, *pAp, *alpha, *beta, *bb, *tol2, *rr;
+  double* rs;             // per-sample power of two ~ 1 / |b| applied to the fp32 residual copies (NULL: none)
   double* xx;             // |x|^2 of the current iterate (AMG path: attainable-accuracy floor), may be NULL
   const double* maxdiag;  // per-sample (Bv entries) max diagonal entry, with xx
   int Bv;
@@ -348,7 +349,7 @@ __device__ inline double sum_partials(const double* __restrict__ part, int nblk,
   return t;
 }
 
-enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3, PH_XX = 4 };
+enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3, PH_XX = 4, PH_SCALE = 5 };
 
 __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double* __restrict__ partA,
                                                          const double* __restrict__ partB, int nblk, int Bp,
@@ -368,7 +369,8 @@ __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double*
     S.alpha[b] = 0.0;
     S.beta[b] = 0.0;
   } else if (phase == PH_ALPHA) {  // a = p.Ap
-    S.alpha[b] = (S.active[b] && a > 0.0) ? S.rz[b] / a : 0.0;
+    // scaled fp32 copies: z, p, Ap carry rs and both dots rs^2; the updates of x and r take alpha / rs
+    S.alpha[b] = (S.active[b] && a > 0.0) ? (S.rz[b] / a) / (S.rs ? S.rs[b] : 1.0) : 0.0;
     if (b == 0) *S.n_active = 0;
   } else if (phase == PH_BETA) {  // a = r.z (new), c = r.r
     if (S.active[b]) {
@@ -393,6 +395,8 @@ __global__ __launch_bounds__(256) void cg_scalar_kernel(int phase, const double*
     }
   } else if (phase == PH_XX) {  // a = x.x
     S.xx[b] = a;
+  } else if (phase == PH_SCALE) {  // a = b.b: power of two rs with rs |b| in [1, 2) (see pcg_cvt_kernel in lattice.hip)
+    S.rs[b] = a > 0.0 ? ldexp(1.0, -ilogb(sqrt(a))) : 1.0;
   } else {  // PH_RELRES: a = |b - A x|^2
     relres[b] = S.bb[b] > 0.0 ? sqrt(a / S.bb[b]) : 0.0;
   }
@@ -592,21 +596,22 @@ __global__ __launch_bounds__(256) void agg_prolong_add_kernel(const TV* __restri
 __global__ __launch_bounds__(256) void amg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                           const double* __restrict__ alpha, double* __restrict__ x,
                                                           double* __restrict__ r, float* __restrict__ r32,
-                                                          double* __restrict__ part_rr, double* __restrict__ part_xx,
-                                                          int n, int Bp) {
+                                                          const double* __restrict__ rs, double* __restrict__ part_rr,
+                                                          double* __restrict__ part_xx, int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
   double s = 0.0, sx = 0.0;
   if (ok) {
     const double a = alpha[nm.b];
+    const double sc = (r32 && rs) ? rs[nm.b] : 1.0;
     for (int i = nm.node0; i < n; i += nm.stride) {
       const i64 o = (i64)i * Bp + nm.b;
       const double xi = x[o] + a * p[o];
       x[o] = xi;
       const double ri = r[o] - a * Ap[o];
       r[o] = ri;
-      if (r32) r32[o] = (float)ri;
+      if (r32) r32[o] = (float)(ri * sc);
       s += ri * ri;
       sx += xi * xi;
     }
@@ -652,12 +657,19 @@ __global__ __launch_bounds__(256) void amg_init_kernel(const double* __restrict_
       const i64 o = (i64)i * Bp + nm.b;
       const double bi = bvec[o];
       x[o] = 0.0; r[o] = bi; p[o] = 0.0;
-      if (r32) r32[o] = (float)bi;
       s += bi * bi;
     }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double t = block_sum_per_sample(s, Bp, lds);
   if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_bb[(i64)blockIdx.x * Bp + nm.b] = t;
+}
+
+__global__ __launch_bounds__(256) void amg_cvt_kernel(const double* __restrict__ r, const double* __restrict__ rs,
+                                                       float* __restrict__ r32, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  const double sc = rs[nm.b];
+  for (int i = nm.node0; i < n; i += nm.stride) r32[(i64)i * Bp + nm.b] = (float)(r[(i64)i * Bp + nm.b] * sc);
 }
 
 constexpr int kAmgMaxLevels = 16;
@@ -845,6 +857,7 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
   S.active = (int*)(sc + 7 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 8 * Bp);
+  S.rs = nullptr;
   S.xx = nullptr;  // plain `tol` stop on this path
   S.maxdiag = nullptr;
   S.Bv = Bv;
@@ -942,6 +955,7 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   S.active = (int*)(sc + 7 * Bp);
   S.iters = iters;
   S.n_active = (int*)(sc + 8 * Bp);
+  S.rs = (precond_fp32 & 1) ? sc + 11 * Bp : nullptr;
   S.xx = (precond_fp32 & 16) ? nullptr : sc + 9 * Bp;  // bit 4: stop on `tol` alone
   S.maxdiag = sc + 10 * Bp;
   S.Bv = Bv;
@@ -969,6 +983,11 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
     else hipLaunchKernelGGL(cg_update_p_kernel<double>, grid, dim3(256), 0, st, (const double*)z, (const double*)S.beta, p, n, Bp);
   };
   hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, r32, p, partC, n, Bp);
+  if (f32) {  // fp32 copy of rs * b, rs ~ 1 / |b| a power of two: keeps the cycle inside the fp32 range
+    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_SCALE, (const double*)partC,
+                       (const double*)nullptr, nblk, Bp, tol, S, relres);
+    hipLaunchKernelGGL(amg_cvt_kernel, grid, dim3(256), 0, st, (const double*)r, (const double*)S.rs, r32, n, Bp);
+  }
   precondition();
   hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, (const double*)partB, (const double*)partC,
                      nblk, Bp, tol, S, relres);
@@ -981,7 +1000,7 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
     hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, (const double*)partA,
                        (const double*)nullptr, nblk, Bp, tol, S, relres);
     hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
-                       (const double*)S.alpha, x, r, r32, partC, S.xx ? partD : (double*)nullptr, n, Bp);
+                       (const double*)S.alpha, x, r, r32, (const double*)S.rs, partC, S.xx ? partD : (double*)nullptr, n, Bp);
     if (S.xx)
       hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_XX, (const double*)partD,
                          (const double*)nullptr, nblk, Bp, tol, S, relres);

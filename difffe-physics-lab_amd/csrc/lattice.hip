@@ -168,6 +168,7 @@ struct Extra {
   const double* dotv;       // M_APPLY, F_NONE: dot (A x + addv) against this vector instead of x
   const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
   float* r32;               // M_RESID, F_NONE, fp64 vectors: also store the residual rounded to fp32 (may be NULL)
+  const double* rscale;     //   ... multiplied by this per-sample power of two first (may be NULL: 1)
   const double* sub;        // M_APPLY, F_NONE: y = A x - sub_scale[b] * sub[i], sub batch-shared (n) (may be NULL)
   const double* sub_scale;  //   per-sample factor of `sub` (NULL: 1)
   const unsigned char* mask;  // M_APPLY, F_NONE: rows with mask[i] != 0 are stored as 0 (may be NULL)
@@ -216,6 +217,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 
   const double inv_omega_in = XFROMB ? 1.0 / omega_in : 0.0;
   const double sub_fac = (MODE == M_APPLY && FUSE == F_NONE && ex.sub && ex.sub_scale) ? ex.sub_scale[b] : 1.0;
+  const double rsc = (MODE == M_RESID && FUSE == F_NONE && ex.r32 && ex.rscale) ? ex.rscale[b] : 1.0;
   const double beta = (FUSE == F_PUPD && !ex.first) ? ex.beta[b] : 0.0;
   const double alpha_prev = (FUSE == F_PUPD && !ex.first) ? ex.alpha[b] : 0.0;
   const TA* __restrict__ aux = (const TA*)ex.a0;
@@ -354,7 +356,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           resrow[k] = res;
         } else if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
-          if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) (ex.r32 + ((i64)row * W + c0w + k) * Bp)[lb] = (float)res;
+          if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) (ex.r32 + ((i64)row * W + c0w + k) * Bp)[lb] = (float)(res * rsc);
           s += res * res;
         } else {
           const double xo = xc[q] + omega * res * dinv;
@@ -674,19 +676,18 @@ __global__ __launch_bounds__(256) void dia_gershgorin_kernel(Level L, int Bv, un
 
 // ---- CG vector kernels ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict__ bvec, double* __restrict__ x,
-                                                        double* __restrict__ r, float* __restrict__ r32,
-                                                        double* __restrict__ part, int n, int Bp) {
+                                                        double* __restrict__ r, double* __restrict__ part, int n,
+                                                        int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double bi = bvec[o];
-    if (x) {  // x == NULL (full-multigrid start): x and r are set after the start, only b.b and the fp32 copy are due
+    if (x) {  // x == NULL (full-multigrid start): x and r are set after the start, only b.b is due here
       x[o] = 0.0;
       r[o] = bi;
     }
-    if (r32) r32[o] = (float)bi;
     s += bi * bi;
   }
   STORE_PARTIAL(part, s);
@@ -695,17 +696,19 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                           const double* __restrict__ alpha, double* __restrict__ x,
                                                           double* __restrict__ r, float* __restrict__ r32,
-                                                          double* __restrict__ part, int n, int Bp) {
+                                                          const double* __restrict__ rs, double* __restrict__ part,
+                                                          int n, int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double a = alpha[nm.b];
+  const double sc = (r32 && rs) ? rs[nm.b] : 1.0;
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     if (x) x[o] += a * p[o];  // x == NULL: the iterate update is fused into the next operator apply
     const double ri = __builtin_nontemporal_load(r + o) - a * __builtin_nontemporal_load(Ap + o);
     __builtin_nontemporal_store(ri, r + o);
-    if (r32) r32[o] = (float)ri;  // read again right away by the V-cycle: left cacheable
+    if (r32) r32[o] = (float)(ri * sc);  // read again right away by the V-cycle: left cacheable
     s += ri * ri;
   }
   STORE_PARTIAL(part, s);
@@ -722,14 +725,16 @@ __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, T
 }
 
 template <typename TV>
-__global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, double* __restrict__ x,
-                                                        double* __restrict__ part, int n, int Bp) {
+__global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, const double* __restrict__ rs,
+                                                        double* __restrict__ x, double* __restrict__ part, int n,
+                                                        int Bp) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
+  const double inv = rs ? 1.0 / rs[nm.b] : 1.0;  // the start was computed from the scaled right-hand side
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double v = (double)x0[o];
+    const double v = (double)x0[o] * inv;
     x[o] = v;
     s += v * v;
   }
@@ -754,11 +759,16 @@ __global__ __launch_bounds__(256) void dia_maxdiag_kernel(Level L, int Bv, unsig
   if ((int)(threadIdx.x & 63) < LB && nm.b < Bv) atomicMax(out + nm.b, (unsigned long long)__double_as_longlong(m));
 }
 
-__global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__ r, float* __restrict__ r32, int n, int Bp) {
+// r32 = fp32(rs * r): the fp32 copies that feed the preconditioner are taken of the residual scaled by a per-sample
+// power of two rs ~ 1 / |b| (S_INIT), so they stay inside the fp32 range whatever the magnitude of the data
+// (forcing of amplitude 1e-35 used to underflow them); powers of two make the scaling exact, so nothing else changes.
+__global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__ r, const double* __restrict__ rs,
+                                                       float* __restrict__ r32, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
+  const double sc = rs ? rs[nm.b] : 1.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    r32[o] = (float)r[o];
+    r32[o] = (float)(r[o] * sc);
   }
 }
 
@@ -789,6 +799,7 @@ __global__ __launch_bounds__(256) void pcg_update_p_kernel(const TV* __restrict_
 // ---- per-sample scalars -----------------------------------------------------------------------
 struct PcgScalars {
   double *rz, *alpha, *beta, *bb, *tol2;
+  double* rs;             // per-sample power of two ~ 1 / |b| applied to the fp32 copies of the residual (NULL: none)
   const double* maxdiag;  // S_FLOOR: per-sample (Bv entries) max diagonal of the unscaled level-0 matrix
   const double* scale;    // S_FLOOR: per-sample operator scale (may be NULL)
   int Bv;
@@ -824,6 +835,7 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
   switch (phase) {
     case S_INIT:  // a = b.b
       S.bb[b] = a;
+      if (S.rs) S.rs[b] = a > 0.0 ? ldexp(1.0, -ilogb(sqrt(a))) : 1.0;  // rs |b| in [1, 2)
       S.tol2[b] = tol * tol * a;
       S.active[b] = a > 0.0 ? 1 : 0;
       S.iters[b] = 0;
@@ -835,7 +847,9 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
       S.rz[b] = a;
       break;
     case S_ALPHA:  // a = p.Ap
-      S.alpha[b] = (S.active[b] && a > 0.0) ? S.rz[b] / a : 0.0;
+      // with scaled fp32 copies z, p and Ap carry the factor rs and both dots rs^2: alpha is unchanged, and the
+      // updates x += alpha p, r -= alpha Ap take alpha / rs
+      S.alpha[b] = (S.active[b] && a > 0.0) ? (S.rz[b] / a) / (S.rs ? S.rs[b] : 1.0) : 0.0;
       if (b == 0) *S.n_active = 0;
       break;
     case S_CONV:  // a = r.r after the update
@@ -1231,6 +1245,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.n_active = (int*)(sc + 6 * Bp);
   const bool use_floor = (precond_fp32 & 16) == 0;  // bit 4 set: stop on `tol` alone
   S.maxdiag = sc + 9 * Bp;  // Bv entries (Bv <= Bp)
+  S.rs = f32 ? sc + 11 * Bp : nullptr;
   S.scale = scale;
   S.Bv = Bv;
   if (use_floor && use_fmg) {
@@ -1259,8 +1274,9 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 
   int nbz = 0, nba = 0;
   const bool light_init = use_fmg && f32;  // the start overwrites x and r; it reads b through r32
-  LAUNCH(pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, r32, partA, n, Bp);
+  LAUNCH(pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
+  if (f32) LAUNCH(pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
   // Fused loop (fine level runs the strip kernels): per iteration
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
@@ -1300,21 +1316,22 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     if (f32) {
       const float* x0 = fmg_start<float>(H, (const float*)r32, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<float>, n, x0, x, use_floor ? partA : (double*)nullptr, n, Bp);
+      LAUNCH(pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x, use_floor ? partA : (double*)nullptr, n, Bp);
     } else {
       const double* x0 = fmg_start<double>(H, b, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<double>, n, x0, x, use_floor ? partA : (double*)nullptr, n, Bp);
+      LAUNCH(pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x, use_floor ? partA : (double*)nullptr, n, Bp);
     }
     if (use_floor) SCALAR(S_FLOOR, partA, nblk);
     const StripGeom gr = strip_geom(L0, Bp);
     if (gr.use && f32) {  // r = b - A x and its fp32 copy in one pass
       Extra ex{};
       ex.r32 = r32;
+      ex.rscale = S.rs;
       launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, nullptr, Bp, gr, st, ex);
     } else {
       op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
-      if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, r32, n, Bp);
+      if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, (const double*)S.rs, r32, n, Bp);
     }
   }
   precondition(1);
@@ -1326,7 +1343,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
     LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
-           r, r32, partA, n, Bp);
+           r, r32, (const double*)S.rs, partA, n, Bp);
     SCALAR(S_CONV, partA, nblk);
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));

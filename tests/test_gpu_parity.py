@@ -884,3 +884,28 @@ def test_lattice_with_many_interior_dirichlet_nodes():
             assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
             assert abs(float(kt.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
             assert rel_err(ft.grad[b].numpy(), dfo) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["auto", "ell"])
+def test_solution_is_invariant_to_the_magnitude_of_the_data(method):
+    """The fp32 copies that feed the multigrid preconditioners are taken of the residual scaled by a per-sample power
+    of two (~ 1 / |b|), so the data may have any magnitude: the same forcing at amplitudes 1e-100 .. 1e100 gives the
+    same iteration counts and (after rescaling) the same solution and gradients to the last digits."""
+    mesh = FEMesh.rectangle(48, 40)
+    rng = np.random.default_rng(3)
+    f0 = 1 + 0.5 * rng.standard_normal((6, mesh.n_nodes))
+    ref = None
+    for amp in (1.0, 1e-100, 1e-35, 1e36, 1e100):
+        k = torch.full((6,), 1.3, dtype=T64, requires_grad=True)
+        solver = DifferentiableFESolver(mesh, k, method=method)
+        u = solver(torch.from_numpy(f0 * amp))
+        (u.sum() / amp).backward()
+        un = u.detach().numpy() / amp
+        info = solver.last_info
+        assert info.not_converged == 0
+        if ref is None:
+            ref = (un, k.grad.clone(), info.iterations, info.adj_iterations)
+            continue
+        assert rel_err(un, ref[0]) < 1e-13 and float((k.grad - ref[1]).abs().max() / ref[1].abs().max()) < 1e-12
+        assert abs(info.iterations - ref[2]) <= 1 and abs(info.adj_iterations - ref[3]) <= 1

@@ -59,10 +59,10 @@ for case in range(n_cases):
     n, m = mesh.n_nodes, mesh.n_elements
     B = int(rng.choice([1, 2, 3, 17, 64, 70])) if not LARGE else int(rng.choice([64, 100, 128, 192]))
     kmode = rng.choice(["scalar", "sample", "elem", "sample_elem"])
+    if kmode in ("sample", "sample_elem") and B == m:
+        B += 1                     # (B,) and (m,) kappa must be distinguishable by shape
     kap = {"scalar": np.array(rng.uniform(0.5, 2.0)), "sample": rng.uniform(0.5, 2.0, B),
            "elem": np.exp(0.4 * rng.standard_normal(m)), "sample_elem": np.exp(0.4 * rng.standard_normal((B, m)))}[kmode]
-    if kmode in ("sample", "sample_elem") and B == m:
-        B += 1
     f = 1 + 0.5 * rng.standard_normal((B, n))
     if rng.random() < 0.3:         # forcing amplitudes spread over 12 decades across the batch (per-sample stops)
         f = f * (10.0 ** rng.uniform(-6, 6, (B, 1)))
