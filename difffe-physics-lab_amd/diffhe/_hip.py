@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdiffhe_hip.so"))
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
+ABI_VERSION = 2     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
 
 
 class MgLevel(C.Structure):
@@ -85,7 +86,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.diffhe_abi_version() != 2:
+        if handle.diffhe_abi_version() != ABI_VERSION:
             raise HipExtensionError("libdiffhe_hip.so ABI version mismatch")
         _lib = handle
     return _lib

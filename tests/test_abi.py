@@ -27,7 +27,13 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(handle, name), name
     L = _hip.lib()
-    assert L.diffhe_abi_version() == 2
+    assert L.diffhe_abi_version() == _hip.ABI_VERSION
     assert L.diffhe_status_string(0) == b"ok"
     assert b"batch" in L.diffhe_status_string(-4)
     assert L.diffhe_cg_workspace_doubles(1000, 64) > 4 * 1000 * 64
+
+
+def test_binding_and_header_agree_on_the_abi_version():
+    import re
+    m = re.search(r"#define\s+DIFFHE_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and int(m.group(1)) == _hip.ABI_VERSION

@@ -38,7 +38,7 @@ def torch_loss(kind, u, data=None):
 
 
 def test_extension_is_loaded():
-    assert _hip.lib().diffhe_abi_version() == 2
+    assert _hip.lib().diffhe_abi_version() == _hip.ABI_VERSION
     assert torch.cuda.is_available()
 
 
