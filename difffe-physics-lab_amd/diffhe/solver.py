@@ -294,7 +294,7 @@ class _Engine:
         _hip.check(L.diffhe_ell_amg_pcg_solve(arr, nl, Bv, _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               min(self.max_iter, 2000), int(opts["n_coarse"]), int(opts["gamma"]),
                                               float(opts["scale"]),
-                                              int(opts.get("fp32", 1)) | ((0 if int(opts.get("floor", 1)) else 1) << 4),
+                                              int(opts.get("fp32", 0)) | ((0 if int(opts.get("floor", 1)) else 1) << 4),
                                               _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters),
                                               _hip.ptr(p.pinned_status), _stream(p.device)), "diffhe_ell_amg_pcg_solve")
@@ -413,7 +413,7 @@ def _solve_forward(solver, kappa, f):
         if solver.method != "ell-jacobi":
             plan.ensure_amg()
             if plan.amg_levels:                      # at least one coarse level: aggregation-AMG PCG
-                ctx.amg = eng.amg_setup(vals, Bv, bool(solver.amg.get("fp32", 1)))
+                ctx.amg = eng.amg_setup(vals, Bv, bool(solver.amg.get("fp32", 0)))
         if ctx.amg is not None:
             info.path = "ell-amgpcg"
             x, its, bad, relres = eng.amg_pcg(ctx.amg, rhs, Bp, Bv, solver.amg)
@@ -617,8 +617,11 @@ class DifferentiableFESolver(nn.Module):
         self.method = method
         # aggregation AMG of the general path: V-cycle (gamma = 1) with the coarse correction scaled by 1.8
         # (over-correction compensates the piecewise-constant interpolation; < 2 keeps the cycle a contraction)
-        # fp32 = 1: the cycle stores its vectors (and reads copies of per-sample matrix values) in fp32, like mg["fp32"]
-        self.amg = dict(n_coarse=16, gamma=1, scale=1.8, fp32=1)
+        # fp32 = 1 stores the cycle's vectors (and reads copies of per-sample matrix values) in fp32, like mg["fp32"]:
+        # +13 % on benign fields, but OFF by default -- this cycle is a much weaker preconditioner than the geometric one
+        # (50-250 iterations), and on high-contrast fields (kappa spanning 1e5) the fp32 roundings inside it stall or
+        # break the CG long before 1e-14 (randomised sweep: 2000 iterations, diverging samples; fp64 cycle: 123)
+        self.amg = dict(n_coarse=16, gamma=1, scale=1.8, fp32=0)
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)
