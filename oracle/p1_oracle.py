@@ -145,44 +145,76 @@ def load_vector(nodes, elements, f, w=None):
     if w is None:
         _, w = element_matrices(nodes, elements)
     F = np.zeros(n)
+    # np.add.at accumulates in index order: element-major with the vertices innermost is the order of the reference's
+    # loops, so F is bit-identical to the reference's (checked against the G5 fixtures)
     if nodes.shape[1] == 1:
-        np.add.at(F, elements[:, 0], w / 2.0 * f[elements[:, 0]])
-        np.add.at(F, elements[:, 1], w / 2.0 * f[elements[:, 1]])
+        vals = (w / 2.0)[:, None] * f[elements]                       # h_e / 2.0 * f[i], solver.py:95-96
+        np.add.at(F, elements.ravel(), vals.ravel())
     else:
-        fc = (f[elements[:, 0]] + f[elements[:, 1]] + f[elements[:, 2]]) / 3.0
-        for p in range(3):
-            np.add.at(F, elements[:, p], w / 3.0 * fc)
+        fc = (f[elements[:, 0]] + f[elements[:, 1]] + f[elements[:, 2]]) / 3.0   # solver.py:143
+        vals = np.repeat((w / 3.0 * fc)[:, None], 3, axis=1)          # area / 3.0 * f_centroid, solver.py:145
+        np.add.at(F, elements.ravel(), vals.ravel())
     return F
+
+
+def local_stiffness(nodes, elements, kappa):
+    """Per-element stiffness contributions with the reference's operation order (each op rounded on its own):
+    1D  k_e = kappa / h_e, [[k,-k],[-k,k]] (solver.py:88-92); 2D  k_pq = kappa * (b_p b_q + c_p c_q) / (4.0 area)
+    = (kappa * t) / (4.0 area) (solver.py:139).  Returns (m, npe, npe); zero for skipped (degenerate) elements."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    elements = np.asarray(elements, dtype=np.int64)
+    m = elements.shape[0]
+    kap = _kappa_per_element(kappa, m)
+    if nodes.shape[1] == 1:
+        h = nodes[elements[:, 1], 0] - nodes[elements[:, 0], 0]
+        k = kap / h
+        ke = np.empty((m, 2, 2))
+        ke[:, 0, 0] = k; ke[:, 0, 1] = -k; ke[:, 1, 0] = -k; ke[:, 1, 1] = k
+        return ke
+    xi, yi = nodes[elements[:, 0], 0], nodes[elements[:, 0], 1]
+    xj, yj = nodes[elements[:, 1], 0], nodes[elements[:, 1], 1]
+    xk, yk = nodes[elements[:, 2], 0], nodes[elements[:, 2], 1]
+    area = 0.5 * np.abs((xj - xi) * (yk - yi) - (xk - xi) * (yj - yi))
+    keep = area >= 1e-15
+    b = np.stack([yj - yk, yk - yi, yi - yj], axis=1)
+    c = np.stack([xk - xj, xi - xk, xj - xi], axis=1)
+    t = b[:, :, None] * b[:, None, :] + c[:, :, None] * c[:, None, :]
+    ke = (kap[:, None, None] * t) / (4.0 * np.where(keep, area, 1.0))[:, None, None]
+    ke[~keep] = 0.0
+    return ke
 
 
 def assemble_dense(nodes, elements, kappa, f):
     """Dense (n,n) K and (n,) F before BCs: the scatter-add loops of
-    solver.py:82-96 (1D) / solver.py:112-145 (2D)."""
+    solver.py:82-96 (1D) / solver.py:112-145 (2D), same operation and accumulation order
+    (element-major, p outer, q inner): bit-identical to the reference's K and F (G5 fixtures)."""
     nodes = np.asarray(nodes, dtype=np.float64)
     elements = np.asarray(elements, dtype=np.int64)
-    n, m = nodes.shape[0], elements.shape[0]
-    k0, w = element_matrices(nodes, elements)
-    ke = _kappa_per_element(kappa, m)[:, None, None] * k0
-    K = np.zeros((n, n))
-    npe = elements.shape[1]
-    for p in range(npe):
-        for q in range(npe):
-            np.add.at(K, (elements[:, p], elements[:, q]), ke[:, p, q])
-    return K, load_vector(nodes, elements, f, w)
-
-
-def assemble_sparse(nodes, elements, kappa, f):
-    """Same system as `assemble_dense`, stored CSR (duplicates summed)."""
-    nodes = np.asarray(nodes, dtype=np.float64)
-    elements = np.asarray(elements, dtype=np.int64)
-    n, m = nodes.shape[0], elements.shape[0]
-    k0, w = element_matrices(nodes, elements)
-    ke = _kappa_per_element(kappa, m)[:, None, None] * k0
+    n = nodes.shape[0]
+    ke = local_stiffness(nodes, elements, kappa)
     npe = elements.shape[1]
     rows = np.repeat(elements[:, :, None], npe, axis=2).ravel()
     cols = np.repeat(elements[:, None, :], npe, axis=1).ravel()
-    K = sp.coo_matrix((ke.ravel(), (rows, cols)), shape=(n, n)).tocsr()
-    return K, load_vector(nodes, elements, f, w)
+    K = np.zeros((n, n))
+    np.add.at(K, (rows, cols), ke.ravel())
+    return K, load_vector(nodes, elements, f)
+
+
+def assemble_sparse(nodes, elements, kappa, f):
+    """Same system as `assemble_dense`, stored CSR; every entry accumulates its contributions in the same
+    (element) order, so the values are bit-identical to the dense ones."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    elements = np.asarray(elements, dtype=np.int64)
+    n = nodes.shape[0]
+    ke = local_stiffness(nodes, elements, kappa)
+    npe = elements.shape[1]
+    rows = np.repeat(elements[:, :, None], npe, axis=2).ravel()
+    cols = np.repeat(elements[:, None, :], npe, axis=1).ravel()
+    uniq, inv = np.unique(rows * n + cols, return_inverse=True)
+    vals = np.zeros(len(uniq))
+    np.add.at(vals, inv, ke.ravel())
+    K = sp.csr_matrix((vals, (uniq // n, uniq % n)), shape=(n, n))
+    return K, load_vector(nodes, elements, f)
 
 
 # ---------------------------------------------------------------------------
@@ -199,13 +231,21 @@ def apply_bc_and_solve(K, F, bc_nodes, bc_vals):
     free = free_nodes(n, bc_nodes)
     u = np.zeros(n)
     u[bc_nodes] = bc_vals
+    # F_free[fi] = F_free[fi] - K[f_node, bc] * g, one Dirichlet node after the other in dict order (solver.py:166-169):
+    # the subtractions are sequential, not F - (sum of products)
+    F_free = F[free].copy()
     if sp is not None and sp.issparse(K):
         K = K.tocsr()
-        F_free = F[free] - (K[free][:, bc_nodes] @ bc_vals if len(bc_nodes) else 0.0)
+        Kfb = K[free][:, bc_nodes].tocsc()
+        for j in range(len(bc_nodes)):
+            lo, hi = Kfb.indptr[j], Kfb.indptr[j + 1]
+            if hi > lo:
+                F_free[Kfb.indices[lo:hi]] -= Kfb.data[lo:hi] * bc_vals[j]
         lu = spla.splu(K[free][:, free].tocsc())
         u[free] = lu.solve(F_free)
         return u, lu
-    F_free = F[free] - (K[np.ix_(free, bc_nodes)] @ bc_vals if len(bc_nodes) else 0.0)
+    for j, b in enumerate(bc_nodes):
+        F_free = F_free - K[free, b] * bc_vals[j]
     u[free] = np.linalg.solve(K[np.ix_(free, free)], F_free)
     return u, None
 
