@@ -59,11 +59,17 @@ __global__ __launch_bounds__(256) void element_integrals_kernel(const double* __
 // ---------------------------------------------------------------------------------------
 // Deterministic row-gather assembly + Dirichlet elimination
 // ---------------------------------------------------------------------------------------
+// REF = true: `local` holds t = b_p b_q + c_p c_q (2D) or 1 / -1 (1D) and `den` holds 4 area (2D) or h (1D); every
+// contribution is formed as (kappa * t) / den with each operation rounded on its own and added in element order --
+// the operation order of the reference's loops (solver.py:88-92, :139-140), so the stored values (and the lifting
+// terms) are bit-identical to the reference's K.  REF = false: kappa * k0 with contracted multiply-adds.
+template <bool REF>
 __global__ __launch_bounds__(256) void assemble_rows_kernel(
-    const double* __restrict__ local, const double* __restrict__ kappa, i64 kse, i64 ksb,
-    const int* __restrict__ ent_ptr, const int* __restrict__ contrib, const int* __restrict__ cols,
+    const double* __restrict__ local, const double* __restrict__ den, const double* __restrict__ kappa, i64 kse,
+    i64 ksb, const int* __restrict__ ent_ptr, const int* __restrict__ contrib, const int* __restrict__ cols,
     const int* __restrict__ store_slot, const unsigned char* __restrict__ is_bc, const double* __restrict__ g,
     double* __restrict__ vals, double* __restrict__ lift, int n, int m, int W, int Bv) {
+#pragma clang fp contract(off)
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
   for (int i = nm.node0; i < n; i += nm.stride) {
@@ -82,7 +88,12 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
         const int code = contrib[c];
         const int e = code >> 4, pq = code & 15;
         const double kap = kappa ? kappa[(i64)e * kse + (i64)nm.b * ksb] : 1.0;
-        v += kap * local[(i64)pq * m + e];  // K[p,q] += kappa * k0[p,q], solver.py:89-92/:137-140
+        if (REF) {
+          const double num = kap * local[(i64)pq * m + e];
+          v = v + num / den[e];  // K[p,q] = K[p,q] + kappa * t / (4 area), solver.py:139-140
+        } else {
+          v = fma(kap, local[(i64)pq * m + e], v);  // K[p,q] += kappa * k0[p,q], solver.py:89-92/:137-140
+        }
       }
       if (row_bc) {
         v = (k == 0) ? 1.0 : 0.0;
@@ -787,8 +798,22 @@ extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa
   if (!local || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
   if (is_bc && !g) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
-  hipLaunchKernelGGL(assemble_rows_kernel, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local, kappa,
-                     kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g, vals, lift, n, m, W, Bv);
+  hipLaunchKernelGGL(assemble_rows_kernel<false>, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local,
+                     (const double*)nullptr, kappa, kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g,
+                     vals, lift, n, m, W, Bv);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_ell_assemble_rows_ref(const double* tnum, const double* den, const double* kappa,
+                                            long long kappa_se, long long kappa_sb, const int* ent_ptr,
+                                            const int* contrib, const int* cols, const int* store_slot,
+                                            const unsigned char* is_bc, const double* g, double* vals, double* lift,
+                                            int n, int m, int W, int Bv, void* stream) {
+  if (!tnum || !den || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
+  if (is_bc && !g) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  hipLaunchKernelGGL(assemble_rows_kernel<true>, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, tnum, den,
+                     kappa, kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g, vals, lift, n, m, W, Bv);
   return diffhe::check_launch();
 }
 

@@ -183,6 +183,29 @@ def coarsening_step(nodes2d: np.ndarray):
     return None
 
 
+def reference_order_integrals(coords: np.ndarray, elems: np.ndarray):
+    """Numerators and denominators of the element stiffness entries in the reference's operation order, computed
+    with numpy (every operation rounded on its own, like torch's): 2D t[pq] = b_p b_q + c_p c_q, den = 4.0 area
+    (solver.py:119-139; skipped elements contribute 0); 1D t = +-1, den = h (solver.py:86-92).  coords (dim, n),
+    elems (npe, m) as uploaded to the device.  Returns (tnum (npe*npe, m), den (m))."""
+    dim = coords.shape[0]
+    e = elems.astype(np.int64)
+    if dim == 1:
+        h = coords[0, e[1]] - coords[0, e[0]]
+        m = e.shape[1]
+        return np.stack([np.ones(m), -np.ones(m), -np.ones(m), np.ones(m)]), h
+    xi, yi = coords[0, e[0]], coords[1, e[0]]
+    xj, yj = coords[0, e[1]], coords[1, e[1]]
+    xk, yk = coords[0, e[2]], coords[1, e[2]]
+    area = 0.5 * np.abs((xj - xi) * (yk - yi) - (xk - xi) * (yj - yi))
+    keep = area >= 1e-15
+    b = np.stack([yj - yk, yk - yi, yi - yj])
+    c = np.stack([xk - xj, xi - xk, xj - xi])
+    t = (b[:, None, :] * b[None, :, :] + c[:, None, :] * c[None, :, :]).reshape(9, -1)
+    t[:, ~keep] = 0.0
+    return t, np.where(keep, 4.0 * area, 1.0)
+
+
 class LatticeLevel:
     """One level of the multigrid hierarchy of a lattice mesh: geometry, element integrals
     and gather lists on the device.  Level l uses every 2^l-th node of the fine mesh."""
@@ -204,6 +227,9 @@ class LatticeLevel:
                                                  _hip.ptr(self.k0), _hip.ptr(m0), _stream(device)),
                    "diffhe_p1_element_integrals")
         self._m0 = m0 if with_load_matrix else None
+        tn, dn = reference_order_integrals(np.ascontiguousarray(nodes2d.reshape(self.n, 2).T),
+                                           lattice_elements(nx, ny).T)
+        self.tnum, self.den = dev(tn), dev(dn)       # reference-order assembly (fine level; kappa folded in)
         # quad-diagonal coupling b-d: local (1,2) of [a,b,d], local (0,2) of [b,c,d]; exactly 0 for
         # right triangles -> 3 stored diagonals instead of 4
         hyp = max(float(self.k0[5, 0::2].abs().max()), float(self.k0[2, 1::2].abs().max()))
@@ -313,6 +339,8 @@ class SolvePlan:
         _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), self.dim, self.n,
                                                  self.m, _hip.ptr(self.k0), _hip.ptr(self.m0), stream),
                    "diffhe_p1_element_integrals")
+        tn, dn = reference_order_integrals(self.coords.cpu().numpy(), self.elems.cpu().numpy())
+        self.tnum, self.den = dev(tn), dev(dn)       # reference-order assembly
         # load matrix M (batch-shared ELL values): F = M f, df = M^T lambda
         self.Mvals = torch.empty((self.W, self.n), dtype=torch.float64, device=device)
         _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self.m0), None, 0, 0, _hip.ptr(self.ent_ptr),

@@ -133,10 +133,11 @@ class _Engine:
                        "diffhe_ell_apply_dirichlet")
             lift.neg_()
         else:
-            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(p.k0), _hip.ptr(kdev), kse, ksb, _hip.ptr(p.ent_ptr),
-                                                  _hip.ptr(p.contrib), _hip.ptr(p.cols), None, _hip.ptr(p.is_bc),
-                                                  _hip.ptr(p.g), _hip.ptr(vals), _hip.ptr(lift), p.n, p.m, p.W, Bv,
-                                                  st), "diffhe_ell_assemble_rows")
+            # reference operation order: values bit-identical to the reference's K (include/diffhe_hip.h)
+            _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(p.tnum), _hip.ptr(p.den), _hip.ptr(kdev), kse, ksb,
+                                                      _hip.ptr(p.ent_ptr), _hip.ptr(p.contrib), _hip.ptr(p.cols), None,
+                                                      _hip.ptr(p.is_bc), _hip.ptr(p.g), _hip.ptr(vals), _hip.ptr(lift),
+                                                      p.n, p.m, p.W, Bv, st), "diffhe_ell_assemble_rows_ref")
         return vals, lift
 
     def load_vector(self, f_nm, lift, Bv, Bp, lift_scale=None, lattice=False):
@@ -223,11 +224,19 @@ class _Engine:
                 kl = kc
             v = torch.empty((lev.nd, lev.n, Bv), dtype=torch.float64, device=p.device)
             lf = torch.empty((lev.n, Bv), dtype=torch.float64, device=p.device) if li == 0 else None
-            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
-                                                  _hip.ptr(lev.contrib), _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
-                                                  _hip.ptr(lev.is_bc), _hip.ptr(p.g if li == 0 else lev.zero_g()),
-                                                  _hip.ptr(v), _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
-                       "diffhe_ell_assemble_rows(lattice)")
+            if li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
+                _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(lev.tnum), _hip.ptr(lev.den), _hip.ptr(kl), kse, ksb,
+                                                          _hip.ptr(lev.ent_ptr), _hip.ptr(lev.contrib),
+                                                          _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
+                                                          _hip.ptr(lev.is_bc), _hip.ptr(p.g), _hip.ptr(v), _hip.ptr(lf),
+                                                          lev.n, lev.m, 7, Bv, st), "diffhe_ell_assemble_rows_ref(lattice)")
+            else:
+                _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
+                                                      _hip.ptr(lev.contrib), _hip.ptr(lev.cols),
+                                                      _hip.ptr(lev.store_slot), _hip.ptr(lev.is_bc),
+                                                      _hip.ptr(p.g if li == 0 else lev.zero_g()), _hip.ptr(v),
+                                                      _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
+                           "diffhe_ell_assemble_rows(lattice)")
             vals.append(v)
             if li == 0:
                 lift = lf

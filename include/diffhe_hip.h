@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 2
+#define DIFFHE_ABI_VERSION 3
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -108,6 +108,16 @@ int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long
                              const int* ent_ptr, const int* contrib, const int* cols, const int* store_slot,
                              const unsigned char* is_bc, const double* g, double* vals, double* lift, int n, int m,
                              int W, int Bv, void* stream);
+
+/* The same gather assembly in the REFERENCE'S OPERATION ORDER: tnum (npe*npe, m) holds t = b_p b_q + c_p c_q (2D;
+ * +-1 in 1D), den (m) holds 4 area (2D; h in 1D), and every contribution is (kappa * t) / den with each operation
+ * rounded on its own (no contracted multiply-adds, a true division), added in element order -- solver.py:88-92,
+ * :139-140 verbatim.  The stored values and the lifting terms are then bit-identical to the reference's K; used
+ * wherever the matrix is assembled with kappa folded in (everything except the factored per-sample-scalar mode). */
+int diffhe_ell_assemble_rows_ref(const double* tnum, const double* den, const double* kappa, long long kappa_se,
+                                 long long kappa_sb, const int* ent_ptr, const int* contrib, const int* cols,
+                                 const int* store_slot, const unsigned char* is_bc, const double* g, double* vals,
+                                 double* lift, int n, int m, int W, int Bv, void* stream);
 
 /* Element-parallel assembly with fp64 global atomics (the literal scatter-add of
  * solver.py:89-92 / :137-140): element integrals are computed from coords and

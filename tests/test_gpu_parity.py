@@ -934,3 +934,47 @@ def test_per_element_gradients_on_rough_data_at_strip_size():
         assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
         assert rel_err(ft.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
         assert rel_err(kt.grad[b].cpu().numpy(), dko) < 0.5 * RTOL_GRAD
+
+
+@pytest.mark.gpu
+def test_assembled_operators_are_bit_identical_to_the_reference_order():
+    """diffhe_ell_assemble_rows_ref forms every contribution as (kappa * t) / (4 area) with separately rounded
+    operations and adds them in element order -- solver.py:139-140 verbatim -- so the values the lattice and the
+    general path store equal, bit for bit, the oracle's K (which reproduces the reference's K bit for bit on the G5
+    fixtures): uniform and skewed mesh, scalar and per-element kappa."""
+    from diffhe.solver import _Engine, K_SCALAR, K_ELEM
+    rng = np.random.default_rng(0)
+    for jitter in (0.0, 0.25):
+        nx, ny = 60, 44
+        base = FEMesh.rectangle(nx, ny, (0, 1.7), (0, 1.0), 0.2)
+        xy = base.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
+        if jitter: xy[1:-1, 1:-1] += rng.uniform(-jitter, jitter, (ny - 1, nx - 1, 2)) * np.array([1.7 / nx, 1.0 / ny])
+        mesh = FEMesh(nodes=torch.from_numpy(xy.reshape(-1, 2)), elements=base.elements, dirichlet_nodes=dict(base.dirichlet_nodes))
+        n, m = mesh.n_nodes, mesh.n_elements
+        plan = get_plan(mesh, torch.device("cuda", 0))
+        eng = _Engine(plan, 1e-12, 100, 1, "gather")
+        for mode, kap in ((K_SCALAR, np.array(1.37)), (K_ELEM, np.exp(0.4 * rng.standard_normal(m)))):
+            vals, Bv, scale, lift, _ = eng.lattice_assemble(torch.from_numpy(kap), mode, 1, 1)
+            v = vals[0].cpu().numpy().reshape(-1, n)
+            K, _ = orc.assemble_sparse(mesh.nodes.numpy(), mesh.elements.numpy(), kap, np.zeros(n)); K = K.tocsr()
+            is_bc = np.zeros(n, bool); is_bc[list(mesh.dirichlet_nodes.keys())] = True
+            W = nx + 1; offs = [0, 1, W, W - 1]; tot = diff = 0
+            for k in range(v.shape[0]):
+                i = np.arange(n - offs[k]); j = i + offs[k]; ok = ~(is_bc[i] | is_bc[j])
+                ref = np.asarray(K[i[ok], j[ok]]).ravel(); got = v[k, i[ok]]; nz = ref != 0
+                tot += nz.sum(); diff += (got[nz] != ref[nz]).sum()
+            assert tot > 0 and diff == 0, (jitter, mode, diff)
+        # general ELL path
+        plan.ensure_ell()
+        kap = np.exp(0.4 * rng.standard_normal(m))
+        kdev, kse, ksb, Bv = eng.kappa_device(torch.from_numpy(kap), K_ELEM, 1, 1)
+        vals, lift = eng.assemble(kdev, kse, ksb, Bv)
+        cols = plan.cols.cpu().numpy(); v = vals.cpu().numpy()[:, :, 0]
+        K, _ = orc.assemble_sparse(mesh.nodes.numpy(), mesh.elements.numpy(), kap, np.zeros(n)); K = K.tocsr()
+        is_bc = np.zeros(n, bool); is_bc[list(mesh.dirichlet_nodes.keys())] = True
+        tot = diff = 0
+        for k in range(plan.W):
+            i = np.arange(n); j = cols[k]; ok = ~(is_bc[i] | is_bc[j]) & ((k == 0) | (j != i))
+            ref = np.asarray(K[i[ok], j[ok]]).ravel(); got = v[k, ok]; nz = ref != 0
+            tot += nz.sum(); diff += (got[nz] != ref[nz]).sum()
+        assert tot > 0 and diff == 0, (jitter, diff)
