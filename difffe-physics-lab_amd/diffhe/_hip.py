@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdiffhe_hip.so"))
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
-ABI_VERSION = 3     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
+ABI_VERSION = 4     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
 
 
 class MgLevel(C.Structure):
@@ -37,8 +37,10 @@ SIGNATURES = {
     "diffhe_abi_version": (_I, []),
     "diffhe_status_string": (C.c_char_p, [_I]),
     "diffhe_last_hip_error": (C.c_char_p, []),
-    "diffhe_chain1d_solve": (_I, [_P, _P, _L, _L, _P, _L, _P, _I, _P, _P, _L, _I, _I, _P, _P]),
-    "diffhe_chain1d_adjoint": (_I, [_P, _P, _L, _L, _P, _L, _P, _L, _P, _I, _P, _L, _P, _L, _P, _I, _I, _P, _P]),
+    "diffhe_chain1d_stage_doubles": (_L, [_I, _I, _I, _I]),
+    "diffhe_chain1d_solve": (_I, [_P, _P, _L, _L, _P, _L, _P, _I, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "diffhe_chain1d_adjoint": (_I, [_P, _P, _L, _L, _P, _L, _P, _L, _P, _I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P,
+                                    _P]),
     "diffhe_p1_element_integrals": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "diffhe_ell_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_rows_ref": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -73,6 +75,9 @@ _lib = None
 
 class HipExtensionError(RuntimeError):
     pass
+
+
+CHAIN_REFERENCE_ORDER = 1   # DIFFHE_CHAIN_REFERENCE_ORDER
 
 
 def lib():

@@ -288,6 +288,7 @@ class SolvePlan:
         if self.is_chain:
             seg = chain_segments(self.n, is_bc)
             self.n_seg = len(seg)
+            self.max_seg_len = int((seg[:, 1] - seg[:, 0]).max())   # elements of the longest segment: kernel choice
             self.seg = dev(seg)
             self.x = self.coords[0].contiguous()
             return

@@ -389,18 +389,20 @@ def _solve_forward(solver, kappa, f):
     ctx.kappa_value = kappa.detach().to(plan.device, torch.float64).reshape(-1)[0] if mode == K_SCALAR else None
 
     if plan.is_chain:
-        info.path = "chain1d-scan"
         L = eng.L
         kdev = kappa.detach().to(plan.device, torch.float64).contiguous()
         ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
         u = torch.empty((B, n), dtype=torch.float64, device=plan.device)
-        stage = None
-        if n - 1 > 10240:                                   # longer chains stage through global memory
-            stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+        # reference-order mode (default): the system the reference assembled in fp64 (rounded diagonal), see chain1d.hip
+        cflags = _hip.CHAIN_REFERENCE_ORDER if solver.chain == "reference" else 0
+        info.path = "chain1d-scan-ref" if cflags else "chain1d-scan"
+        ns = L.diffhe_chain1d_stage_doubles(n, B, plan.max_seg_len, cflags)   # 0: every segment fits the registers
+        stage = torch.empty(ns, dtype=torch.float64, device=plan.device) if ns > 0 else None
         _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
                                           n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
-                                          _hip.ptr(u), n, n, B, _hip.ptr(stage), _stream(plan.device)),
-                   "diffhe_chain1d_solve")
+                                          _hip.ptr(u), n, n, B, plan.max_seg_len, cflags, _hip.ptr(stage),
+                                          _stream(plan.device)), "diffhe_chain1d_solve")
+        ctx.chain_flags = cflags
         ctx.saved = (kdev, ksb, kse, u)
     elif lattice:
         info.path = "lattice-mgpcg"
@@ -466,13 +468,13 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
         dk_e = torch.empty((B, m), dtype=torch.float64, device=plan.device) if want_e else None
         part = torch.empty((B, plan.n_seg), dtype=torch.float64, device=plan.device)
-        stage = None
-        if n - 1 > 10240:                                   # longer chains stage through global memory
-            stage = torch.empty(B * plan.n_seg * 2 * (n - 1), dtype=torch.float64, device=plan.device)
+        ns = L.diffhe_chain1d_stage_doubles(n, B, plan.max_seg_len, ctx.chain_flags)
+        stage = torch.empty(ns, dtype=torch.float64, device=plan.device) if ns > 0 else None
         _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(g_dev), n,
                                             _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(df), n,
-                                            _hip.ptr(dk_e), m, _hip.ptr(part), n, B, _hip.ptr(stage),
-                                            _stream(plan.device)), "diffhe_chain1d_adjoint")
+                                            _hip.ptr(dk_e), m, _hip.ptr(part), n, B, plan.max_seg_len,
+                                            ctx.chain_flags, _hip.ptr(stage), _stream(plan.device)),
+                   "diffhe_chain1d_adjoint")
         dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
         dk_elem = dk_e
     else:
@@ -529,7 +531,6 @@ def _solve_backward(ctx, gbar, need_k, need_f):
 _SOLVERS: "weakref.WeakValueDictionary[int, DifferentiableFESolver]" = weakref.WeakValueDictionary()
 _STATES: Dict[int, object] = {}
 _TOKENS = itertools.count(1)
-_MAX_PENDING_STATES = 64    # safety valve only: states normally live exactly as long as their autograd graph
 
 
 class _StateGuard:
@@ -553,9 +554,7 @@ def fe_solve(kappa: torch.Tensor, f: torch.Tensor, handle: int, save: bool) -> T
     token = 0
     if save:
         token = next(_TOKENS)
-        _STATES[token] = state
-        while len(_STATES) > _MAX_PENDING_STATES:
-            _STATES.pop(next(iter(_STATES)))
+        _STATES[token] = state     # freed with the autograd graph of this solve (_StateGuard): no cap on pending solves
     return u, torch.tensor(token, dtype=torch.int64)
 
 
@@ -576,8 +575,7 @@ def fe_solve_backward(gbar: torch.Tensor, token: torch.Tensor, need_k: bool, nee
     """(dL/dkappa, dL/df) for the forward call named by `token`; unused gradients come back empty."""
     state = _STATES.get(int(token))
     if state is None:
-        raise RuntimeError("diffhe: adjoint state of this solve is gone (its autograd graph was freed, or more than "
-                           f"{_MAX_PENDING_STATES} differentiated solves are alive at once)")
+        raise RuntimeError("diffhe: adjoint state of this solve is gone (its autograd graph was freed)")
     gk, gf = _solve_backward(state, gbar, need_k, need_f)
     return (gk if gk is not None else kappa_like.new_empty(0), gf if gf is not None else f_like.new_empty(0))
 
@@ -612,7 +610,7 @@ class DifferentiableFESolver(nn.Module):
     ----------
     mesh : FEMesh
     kappa : float or torch.Tensor -- diffusion coefficient (see module docstring).
-    device, tol, max_iter, check_every, assembly, method, mg : HIP-path knobs (ours; the
+    device, tol, max_iter, check_every, assembly, method, mg, chain : HIP-path knobs (ours; the
         reference has none).  `assembly` is "gather" (deterministic) or "atomic" (general
         path); `method="ell"` forces the general ELL path on lattice meshes; `mg` overrides
         the multigrid parameters (nu, n_coarse, omega) of the lattice path.
@@ -620,7 +618,7 @@ class DifferentiableFESolver(nn.Module):
 
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
-                 mg: Optional[dict] = None):
+                 mg: Optional[dict] = None, chain: str = "reference"):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -631,6 +629,12 @@ class DifferentiableFESolver(nn.Module):
             raise ValueError(f"Unknown assembly: {assembly!r}")
         if method not in ("auto", "ell", "ell-jacobi"):
             raise ValueError(f"Unknown method: {method!r}")
+        if chain not in ("reference", "exact"):
+            raise ValueError(f"Unknown chain mode: {chain!r}")
+        # 1D chains: "reference" reproduces the solution of the matrix the reference assembles in fp64 (its rounded
+        # diagonal costs 4e-10 in u at 10^4 elements); "exact" is the plain scan, 1e-15 from the exact solution of the
+        # unrounded system and ~1.5x faster
+        self.chain = chain
         # "ell": general path (aggregation-AMG PCG) even on lattice meshes; "ell-jacobi": general path
         # with the plain Jacobi preconditioner
         self.method = method

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 3
+#define DIFFHE_ABI_VERSION 4
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -55,24 +55,40 @@ const char* diffhe_last_hip_error(void);
  *            (bit0: first node is Dirichlet, bit1: last node is Dirichlet)
  *   g        (n) Dirichlet values (0 at free nodes)
  *   u        (B, n) out, row stride ldu
- *   stage    global staging buffer, (B * n_seg) * 2 * (n - 1) doubles, used only when
- *            n - 1 > 10240 (shorter chains are solved in registers; may be NULL then;
- *            DIFFHE_E_TOOBIG if it is needed and NULL)
+ *   max_seg_len  elements of the longest segment (1 .. n-1): selects the kernel.  Segments up to
+ *            10 240 elements are solved in registers; longer ones stage through `stage`.
+ *   flags    DIFFHE_CHAIN_REFERENCE_ORDER: solve the system the reference ASSEMBLED in fp64 --
+ *            weights k_e = fl(kappa_e/h_e), diagonal fl(k_{i-1} + k_i) (solver.py:88-92), load
+ *            fl(fl(h/2) f_i) summed in element order (solver.py:95-96) -- by correcting the exact
+ *            scan solution to first order in the diagonal's rounding error (a second scan in the
+ *            same kernel; see chain1d.hip).  Measured 7e-12 from torch.linalg.solve at N = 1e4,
+ *            where the plain scan -- which solves the unrounded weighted Laplacian to 1e-15 -- is
+ *            4e-10 away.  0: plain scan.
+ *   stage    global staging buffer of diffhe_chain1d_stage_doubles(...) doubles (0 when every
+ *            segment fits the register kernel: may be NULL then; DIFFHE_E_TOOBIG if needed and NULL)
  * ---------------------------------------------------------------------------- */
+#define DIFFHE_CHAIN_REFERENCE_ORDER 1
+
+long long diffhe_chain1d_stage_doubles(int n, int B, int max_seg_len, int flags);
+
 int diffhe_chain1d_solve(const double* x, const double* kappa, long long kappa_sb, long long kappa_se,
                          const double* rhs, long long rhs_sb, const int* seg, int n_seg, const double* g,
-                         double* u, long long ldu, int n, int B, double* stage, void* stream);
+                         double* u, long long ldu, int n, int B, int max_seg_len, int flags, double* stage,
+                         void* stream);
 
 /* Adjoint of the above (reverse of solver.py:89-96,169-181):
  *   lambda = K_free^{-1} gbar_free (lambda = 0 on Dirichlet nodes);
  *   df[b,i]      = lambda_i * sum_{e ni i} h_e/2
  *   dkappa_e[b,e] = -(lambda_{e+1}-lambda_e)(u_{e+1}-u_e)/h_e        (optional, may be NULL)
  *   dkappa_part[b*n_seg + s] = sum over the elements of segment s of dkappa_e
+ * With DIFFHE_CHAIN_REFERENCE_ORDER lambda is the solution of the reference's rounded matrix (what
+ * autograd's LinalgSolveExBackward computes), same correction as the forward solve.
  */
 int diffhe_chain1d_adjoint(const double* x, const double* kappa, long long kappa_sb, long long kappa_se,
                            const double* gbar, long long gbar_sb, const double* u, long long ldu,
                            const int* seg, int n_seg, double* df, long long lddf, double* dkappa_e,
-                           long long lddk, double* dkappa_part, int n, int B, double* stage, void* stream);
+                           long long lddk, double* dkappa_part, int n, int B, int max_seg_len, int flags,
+                           double* stage, void* stream);
 
 /* ------------------------------------------------------------------------------
  * General P1 path (any 1D/2D mesh): per-element integrals, deterministic gather

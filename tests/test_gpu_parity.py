@@ -218,7 +218,7 @@ def test_chain_with_interior_and_one_sided_dirichlet():
         ft = torch.from_numpy(f).requires_grad_(True)
         solver = DifferentiableFESolver(mesh, kt)
         u = solver(ft)
-        assert solver.last_info.path == "chain1d-scan"
+        assert solver.last_info.path == "chain1d-scan-ref"      # default: the reference's rounded system
         (u ** 2).sum().backward()
         uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap, f, lambda u: 2 * u)
         assert rel_err(u.detach().numpy(), uo) < RTOL_U
@@ -277,37 +277,87 @@ def test_physics_loss_fem_match_value_and_cache():
 
 
 def test_config2_shape_1d_10000():
-    """BASELINE config 2 shape: 1D 10 000 elements, RHS ensemble, fwd + adjoint."""
-    mesh = FEMesh.line(10_000)
+    """BASELINE config 2 at its stated size -- 1D, 10 000 elements, 1024 right-hand sides, fwd + adjoint -- against
+    the REFERENCE ITSELF: fixture G10 holds rows 0, 1, 1023 of the reference's own solve (dense assembly +
+    torch.linalg.solve, solver.py:73-98,153-183) of exactly this batch.  Strict 1e-10, no relaxed clause.
+    cond(K) ~ 4e7 here; what makes the difference is the rounded diagonal fl(k_{i-1} + k_i) of the matrix the
+    reference assembles (4e-10 in u): the default chain mode solves THAT system (chain1d.hip)."""
+    g = golden("g10_config2_1d_10000")
+    mesh = FEMesh.line(int(g["n_elements"]))
     nodes, el, bn, bv = arrays(mesh)
-    B = 64
-    gen = torch.Generator().manual_seed(1234)
+    B = int(g["batch"])
+    assert B == 1024
+    gen = torch.Generator().manual_seed(int(g["seed"]))
     f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
-    k = torch.tensor(1.0, dtype=T64, requires_grad=True)
+    for i, row in enumerate(g["rows"]):                      # same inputs as the reference saw
+        assert np.array_equal(f[int(row)].numpy(), g["f"][i])
+    k = torch.ones(B, dtype=T64, requires_grad=True)         # kappa = 1, one gradient per right-hand side
     fc = f.cuda().requires_grad_(True)
-    u = DifferentiableFESolver(mesh, k)(fc)
-    assert u.is_cuda
+    solver = DifferentiableFESolver(mesh, k)
+    u = solver(fc)
+    assert u.is_cuda and solver.last_info.path == "chain1d-scan-ref"
     loss = 0.5 * (u ** 2).sum() / B
     loss.backward()
-    # cond(K) ~ 4e7 here: the fp64 LU the reference runs is itself ~4e-10 off the exact
-    # discrete solution (oracle/p1_oracle.py:chain_solve_longdouble), so parity at this size
-    # is judged against the extended-precision restatement; the fp64 oracle must agree with
-    # us no worse than it agrees with that.
-    for b in (0, 17, 63):
-        ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, 1.0, f[b].numpy(), lambda u: u / B)
-        ub = u[b].detach().cpu().numpy()
-        assert rel_err(ub, ux) < RTOL_U
-        assert rel_err(fc.grad[b].cpu().numpy(), dfx) < RTOL_GRAD
-        if b == 0:
-            uo = orc.solve(nodes, el, bn, bv, 1.0, f[b].numpy(), sparse=True)
-            assert rel_err(ub, uo) <= 2.0 * rel_err(uo, ux) + 1e-12
-    # analytic identity: dL/dkappa = -<gbar,u>/kappa (Appendix B)
+    uh = u.detach().cpu().numpy()
+    worst = 0.0
+    for i, row in enumerate(g["rows"]):
+        worst = max(worst, rel_err(uh[int(row)], g["u"][i]))
+    print(f"config 2: max rel err vs the reference's torch.linalg.solve over rows {list(g['rows'])}: {worst:.2e}")
+    assert worst < RTOL_U
+    # gradients (the reference's backward is O(N^3): infeasible at this size) against the fp64 oracle, which
+    # reproduces the reference's u on these rows to 1e-14 (tests/test_oracle_golden.py) -- strict as well
+    dfh = fc.grad.cpu().numpy()
+    for b in (0, 1, 511, 1023):
+        uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, 1.0, f[b].numpy(), lambda u_: u_ / B, sparse=True)
+        assert rel_err(uh[b], uo) < RTOL_U
+        assert rel_err(dfh[b], dfo) < RTOL_GRAD
+        assert abs(float(k.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
+    # analytic identity dL/dkappa = -<gbar,u>/kappa (Appendix B): exact for the UNROUNDED system only -- for the
+    # matrix the reference assembles it holds to cond * eps (measured 3.6e-10 here, on the oracle alike)
     ref = -float((u.detach() ** 2).sum() / B)
-    assert abs(float(k.grad) - ref) <= 1e-10 * abs(ref)
-    # f == 1: u = x(1-x)/2 at the nodes
+    assert abs(float(k.grad.sum()) - ref) <= 2e-9 * abs(ref)
+    # f == 1: u = x(1-x)/2 at the nodes.  The reference's own solve is 4e-10 from that identity at this size (its
+    # rounded diagonal); the plain scan (chain="exact") solves the unrounded system and meets it to 1e-14.
     x = mesh.nodes.squeeze(1)
-    u1 = DifferentiableFESolver(mesh)(torch.ones_like(x))
-    assert float((u1 - x * (1 - x) / 2).abs().max()) < 1e-10 * 0.125
+    u1 = DifferentiableFESolver(mesh, chain="exact")(torch.ones_like(x))
+    assert float((u1 - x * (1 - x) / 2).abs().max()) < 1e-13 * 0.125
+
+
+def test_config2_exact_scan_mode_against_extended_precision():
+    """chain="exact": the plain scan solves the UNROUNDED weighted Laplacian; judged against the extended-precision
+    restatement (oracle.chain_solve_longdouble).  It is 4e-10 away from the reference at this size -- measured
+    here and required to be outside the tolerance, so that the two modes cannot be confused."""
+    g = golden("g10_config2_1d_10000")
+    mesh = FEMesh.line(10_000)
+    nodes, el, bn, bv = arrays(mesh)
+    f = torch.from_numpy(g["f"])
+    fc = f.cuda().requires_grad_(True)
+    k = torch.tensor(1.0, dtype=T64, requires_grad=True)
+    solver = DifferentiableFESolver(mesh, k, chain="exact")
+    u = solver(fc)
+    assert solver.last_info.path == "chain1d-scan"
+    (0.5 * (u ** 2).sum()).backward()
+    for b in range(f.shape[0]):
+        ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, 1.0, f[b].numpy(), lambda u_: u_)
+        assert rel_err(u[b].detach().cpu().numpy(), ux) < 1e-13
+        assert rel_err(fc.grad[b].cpu().numpy(), dfx) < 1e-12
+        d = rel_err(u[b].detach().cpu().numpy(), g["u"][b])
+        assert 1e-10 < d < 1e-9, d
+
+
+def test_1d_gradients_at_2000_elements_vs_reference_autograd():
+    """G13: u, dL/dkappa, dL/df from the reference's own autograd at 2000 elements (cond 1.6e6)."""
+    g = golden("g13_1d_grad_2000")
+    mesh = FEMesh.line(int(g["n_elements"]))
+    k = torch.tensor(float(g["kappa"]), dtype=T64, requires_grad=True)
+    f = torch.from_numpy(g["f"]).requires_grad_(True)
+    u = DifferentiableFESolver(mesh, k)(f)
+    L = (u ** 2).sum()
+    L.backward()
+    assert rel_err(u.detach().numpy(), g["u"]) < RTOL_U
+    assert abs(float(L) - float(g["loss"])) < RTOL_U * abs(float(g["loss"]))
+    assert abs(float(k.grad) - float(g["dkappa"])) < RTOL_GRAD * abs(float(g["dkappa"]))
+    assert rel_err(f.grad.numpy(), g["df"]) < RTOL_GRAD
 
 
 def test_lattice_graded_mesh_and_per_element_kappa_all_levels():
@@ -756,8 +806,16 @@ def test_unstructured_mesh_amg_vs_oracle(N, B):
         assert its_amg * 3 < sj.last_info.iterations, (its_amg, sj.last_info.iterations)
 
 
+def _chain_oracle(mode, nodes, el, bn, bv, kappa, f, gbar_fn):
+    """reference mode: the fp64 oracle (the reference's rounded system, LU); exact mode: extended precision."""
+    if mode == "reference":
+        return orc.solve_with_adjoint(nodes, el, bn, bv, kappa, f, gbar_fn, sparse=True)
+    return orc.chain_solve_longdouble(nodes, bn, bv, kappa, f, gbar_fn)
+
+
 @pytest.mark.gpu
-def test_long_chain_global_staging_path():
+@pytest.mark.parametrize("mode", ["reference", "exact"])
+def test_long_chain_global_staging_path(mode):
     """Chains longer than 10 240 elements leave the register kernel for the globally staged one."""
     mesh = FEMesh.line(12_345)
     nodes, el, bn, bv = arrays(mesh)
@@ -766,18 +824,19 @@ def test_long_chain_global_staging_path():
     f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
     k = torch.tensor([0.7, 1.0, 1.9], dtype=T64, requires_grad=True)
     fc = f.cuda().requires_grad_(True)
-    u = DifferentiableFESolver(mesh, k)(fc)
+    u = DifferentiableFESolver(mesh, k, chain=mode)(fc)
     (0.5 * (u ** 2).sum()).backward()
     for b in range(B):
-        ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, float(k[b]), f[b].numpy(), lambda u: u)
+        ux, dkx, dfx = _chain_oracle(mode, nodes, el, bn, bv, float(k[b]), f[b].numpy(), lambda u: u)
         assert rel_err(u[b].detach().cpu().numpy(), ux) < RTOL_U
         assert rel_err(fc.grad[b].cpu().numpy(), dfx) < RTOL_GRAD
         assert abs(float(k.grad[b]) - dkx.sum()) < RTOL_GRAD * abs(dkx.sum())
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reference", "exact"])
 @pytest.mark.parametrize("N", [255, 256, 257, 1024, 1025, 4096, 4097, 10240, 10241])
-def test_chain_kernel_size_boundaries(N):
+def test_chain_kernel_size_boundaries(N, mode):
     """Each register-kernel instantiation at its largest size and the next kernel at its smallest,
     per-element kappa, non-uniform nodes, an interior Dirichlet node and a Neumann right end."""
     rng = np.random.default_rng(N)
@@ -788,13 +847,29 @@ def test_chain_kernel_size_boundaries(N):
     kap = torch.from_numpy(rng.uniform(0.5, 2.0, N)).requires_grad_(True)
     f = torch.from_numpy(1 + 0.3 * rng.standard_normal(N + 1))
     fc = f.cuda().requires_grad_(True)
-    u = DifferentiableFESolver(mesh, kap)(fc)
+    u = DifferentiableFESolver(mesh, kap, chain=mode)(fc)
     w = rng.standard_normal(N + 1)
     (torch.from_numpy(w).cuda() * u).sum().backward()
-    ux, dkx, dfx = orc.chain_solve_longdouble(nodes, bn, bv, kap.detach().numpy(), f.numpy(), lambda u: w)
+    ux, dkx, dfx = _chain_oracle(mode, nodes, el, bn, bv, kap.detach().numpy(), f.numpy(), lambda u: w)
     assert rel_err(u.detach().cpu().numpy(), ux) < RTOL_U
     assert rel_err(fc.grad.cpu().numpy(), dfx) < RTOL_GRAD
     assert rel_err(kap.grad.numpy(), dkx) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+def test_many_pending_differentiated_solves_one_backward():
+    """100 unbatched solves summed into one loss, a single backward: every adjoint state stays alive with its graph
+    (there is no cap on pending solves)."""
+    mesh = FEMesh.line(24)
+    k = torch.tensor(1.3, dtype=T64, requires_grad=True)
+    gen = torch.Generator().manual_seed(3)
+    fs = 1 + 0.5 * torch.randn(100, mesh.n_nodes, generator=gen, dtype=T64)
+    solver = DifferentiableFESolver(mesh, k)
+    total = sum((solver(fs[i]) ** 2).sum() for i in range(100))
+    total.backward()
+    kb = torch.tensor(1.3, dtype=T64, requires_grad=True)
+    (DifferentiableFESolver(mesh, kb)(fs) ** 2).sum().backward()          # the same as one batched solve
+    assert abs(float(k.grad) - float(kb.grad)) < 1e-12 * abs(float(kb.grad))
 
 
 @pytest.mark.gpu

@@ -40,17 +40,20 @@ def chain():
     df = torch.empty_like(f)
     part = torch.empty(B, plan.n_seg, dtype=torch.float64, device=dev)
     kap = torch.ones(1, dtype=torch.float64, device=dev)
-    t = timeit(lambda: _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(f), n,
-                                                         _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g), _hip.ptr(u),
-                                                         n, n, B, None, st), "fwd"))
-    print(f"chain1d forward  N=10000 B={B}: {t*1e6:8.1f} us  {16 * n * B / t / 1e9:8.1f} GB/s (16n B/sample)  "
-          f"{B / t:.3e} solves/s")
-    t2 = timeit(lambda: _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(g), n,
-                                                            _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg,
-                                                            _hip.ptr(df), n, None, 0, _hip.ptr(part), n, B, None, st),
-                                  "adj"))
-    print(f"chain1d adjoint  N=10000 B={B}: {t2*1e6:8.1f} us  {24 * n * B / t2 / 1e9:8.1f} GB/s (24n B/sample)  "
-          f"fwd+adj {B / (t + t2):.3e} differentiable solves/s, {40 * n * B / (t + t2) / 1e9:.1f} GB/s of 40n")
+    msl = plan.max_seg_len
+    for flags, name in ((_hip.CHAIN_REFERENCE_ORDER, "reference-order (default)"), (0, "exact scan")):
+        t = timeit(lambda: _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(f), n,
+                                                             _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
+                                                             _hip.ptr(u), n, n, B, msl, flags, None, st), "fwd"))
+        print(f"chain1d {name:26s} forward  N=10000 B={B}: {t*1e6:8.1f} us  {16 * n * B / t / 1e9:8.1f} GB/s "
+              f"(16n B/sample)  {B / t:.3e} solves/s")
+        t2 = timeit(lambda: _hip.check(L.diffhe_chain1d_adjoint(_hip.ptr(plan.x), _hip.ptr(kap), 0, 0, _hip.ptr(g), n,
+                                                                _hip.ptr(u), n, _hip.ptr(plan.seg), plan.n_seg,
+                                                                _hip.ptr(df), n, None, 0, _hip.ptr(part), n, B, msl,
+                                                                flags, None, st), "adj"))
+        print(f"chain1d {name:26s} adjoint  N=10000 B={B}: {t2*1e6:8.1f} us  {24 * n * B / t2 / 1e9:8.1f} GB/s "
+              f"(24n B/sample)  fwd+adj {B / (t + t2):.3e} differentiable solves/s, "
+              f"{40 * n * B / (t + t2) / 1e9:.1f} GB/s of 40n")
 
 
 def main():
