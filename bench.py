@@ -7,15 +7,22 @@ Workload (BASELINE.json metric / SURVEY 8(d) C4): FEMesh.rectangle(1024, 1024), 
 per GPU, one scalar kappa_b ~ U(0.5, 2.0) per sample (seed 4096 + rank), f == 1,
 L = mean_b sum_i u_b[i]^2.  One "step" = assemble K(kappa_b), F; forward solve; dL/du;
 adjoint solve; dL/dkappa contraction -- for every sample of the batch.  Inputs are resident
-in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, RCCL), the
-batch is sharded (weak scaling: 256 per GPU), the only collective is the loss all-reduce.
+in HBM before the timed region.
+
+N > 1: one process per GPU over torch.distributed (RCCL).  Under `torch.distributed.run` the ranks come
+from the environment; a plain `python bench.py --gpus N` starts the N rank processes ITSELF (fresh children,
+before this process touches the GPU) and relays rank 0's JSON line.  The batch is sharded (weak scaling:
+256 per GPU) through `diffhe.distributed.ShardedBatchSolve`; the only collective is the fused loss all-reduce.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
-dominant kernel and `cpu_baseline` (the CPU oracle timed on the host cores, rank 0, N = 1).
+dominant kernel (+ the step-level figure), and `cpu_baseline` (CPU restatements of the reference path timed on
+the host cores, rank 0, N = 1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,14 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "difffe-physics-lab_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
@@ -47,17 +50,55 @@ def parse():
     ap.add_argument("--kappa", choices=["sample", "element"], default="sample",
                     help="sample: one scalar kappa per sample (the contract workload); element: a log-normal "
                          "per-element field per sample, exp(0.3 randn) (SURVEY 8(d) C3/C4 variant)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercise launch, rendezvous, barriers and the max-over-ranks timing only "
+                         "(value is null); used by the CPU tests of the multi-rank launch path")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and wait.
+    Nothing in this process has initialised the GPU (no torch.cuda call, torch is not even imported yet), and the
+    children are new interpreters, not re-execs.  Rank 0 inherits stdout, so its JSON line is this command's."""
+    port = _free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if args.dry_run:
+        return dry_run(args, rank, world, dist, torch)
+
     if args.all_on_device is not None:
         local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
@@ -68,7 +109,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    import ctypes
     from diffhe import FEMesh, DifferentiableFESolver, _hip
+    from diffhe.distributed import ShardedBatchSolve
     from diffhe.plan import get_plan, padded_batch
 
     N, B = args.mesh, args.batch
@@ -84,18 +127,21 @@ def main():
     f = torch.ones(B, n, dtype=torch.float64, device=dev)
     solver = DifferentiableFESolver(mesh, kappa, device=dev, **({"tol": args.tol} if args.tol else {}))
     plan = get_plan(mesh, dev)
+    L = _hip.lib()
 
+    # per-rank differentiable solve of this rank's shard: the HIP path (`solver` holds this rank's kappa shard)
+    driver = ShardedBatchSolve(lambda kap, f_local: solver(f_local))
+    assert driver.world == world
     iters = []
 
     def step():
         kappa.grad = None
-        u = solver(f)
-        loss = (u ** 2).sum(dim=1).mean()
-        loss.backward()
+        # global mean loss; per-sample kappa: no gradient reduction, ONE fused all-reduce of the scalar loss
+        loss, u = driver.step_local(f, B * world, lambda u_: (u_ ** 2).sum(), kappa)
         info = solver.last_info
         iters.append((info.iterations, info.adj_iterations, info.max_relres, info.adj_max_relres,
                       info.not_converged))
-        return loss.detach(), u
+        return loss, u
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -106,20 +152,21 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    # dominant kernel (fused CG step) timed with HIP events INSIDE the solver loop, over the timed region only
-    import ctypes
+    # dominant kernel (fused CG step) timed with HIP events INSIDE the solver loop, over the timed region only;
+    # algorithmic bytes of every launch of the timed steps from the library's own accounting
     prof_ms, prof_n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+    acc_bytes, acc_launches = ctypes.c_double(0.0), ctypes.c_longlong(0)
     if rank == 0:
-        _hip.lib().diffhe_lattice_pcg_profile(1, None, None)
+        L.diffhe_lattice_pcg_profile(1, None, None)
+    L.diffhe_traffic_account(1, None, None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, u = step()
-        if world > 1:
-            dist.all_reduce(loss)       # the only collective: scalar loss (per-sample kappa)
     sync_all()
     elapsed = time.perf_counter() - t0
+    L.diffhe_traffic_account(1, ctypes.byref(acc_bytes), ctypes.byref(acc_launches))
     if rank == 0:
-        _hip.lib().diffhe_lattice_pcg_profile(0, ctypes.byref(prof_ms), ctypes.byref(prof_n))
+        L.diffhe_lattice_pcg_profile(0, ctypes.byref(prof_ms), ctypes.byref(prof_n))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -127,18 +174,21 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     value = world * B * args.steps / elapsed
     timed_iters = list(iters[-args.steps:]) if args.steps else list(iters)
+    lattice = solver.last_info.path == "lattice-mgpcg"
 
-    # secondary measurement, same run: V-cycle vectors stored in fp64 instead of fp32
+    # secondary measurements, same run: V-cycle vectors stored fp64; per-element kappa field per sample
     variant = None
-    if (world == 1 and solver.last_info.path == "lattice-mgpcg" and solver.mg.get("fp32") and args.kappa == "sample"
-            and not args.no_variants):
+    if world == 1 and lattice and solver.mg.get("fp32") and args.kappa == "sample" and not args.no_variants:
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize(dev)
+            tv = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - tv
+
         solver.mg["fp32"] = 0
-        step()
-        torch.cuda.synchronize(dev)
-        tv = time.perf_counter()
-        step()
-        torch.cuda.synchronize(dev)
-        tv = time.perf_counter() - tv
+        tv = timed(step)
         variant = {"vcycle_storage_fp64": {"value_per_gpu": round(B / tv, 3), "ms_per_step": round(1e3 * tv, 3),
                                            "iters_fwd": solver.last_info.iterations}}
         solver.mg["fp32"] = 1
@@ -154,12 +204,7 @@ def main():
             ue = solver_e(f)
             (ue ** 2).sum(dim=1).mean().backward()
 
-        step_e()
-        torch.cuda.synchronize(dev)
-        tv = time.perf_counter()
-        step_e()
-        torch.cuda.synchronize(dev)
-        tv = time.perf_counter() - tv
+        tv = timed(step_e)
         variant["kappa_element_field"] = {
             "value_per_gpu": round(B / tv, 3), "ms_per_step": round(1e3 * tv, 3),
             "iters_fwd": solver_e.last_info.iterations, "iters_adj": solver_e.last_info.adj_iterations,
@@ -167,128 +212,22 @@ def main():
         del solver_e, kap_e
         torch.cuda.empty_cache()
 
-    out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: the batched operator apply of the CG loop ----
-        L = _hip.lib()
-        Bp = padded_batch(B)
-        roof = None
-        traffic = None
-        copy_gbs = None
-        # the fused CG step (and its roofline entry) exists for wave-sized batches on strip-sized meshes only
-        roofline_ok = (solver.last_info.path == "lattice-mgpcg" and args.kappa == "sample" and Bp >= 64
-                       and N >= 191) or solver.last_info.path == "ell-pcg"
-        st = torch.cuda.current_stream(dev).cuda_stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-        def time_launch(launch):
-            for _ in range(3):
-                launch()
-            e0.record()
-            for _ in range(args.kernel_reps):
-                launch()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
-
-        other = None
-        if roofline_ok and solver.last_info.path == "lattice-mgpcg":
-            # The kernel with the largest share of the step (profiles/r01_mgpcg_final_kernel_stats.csv) is the
-            # fused CG step dia_strip_kernel<M_APPLY, F_PUPD> (p = z + beta p, x += alpha p_old, Ap = A p, p.Ap);
-            # it is timed alone on the operator this workload assembles (shared unit matrix + kappa_b scale).
-            from diffhe.solver import _Engine, K_SAMPLE
-            eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
-            vals, Bv, scale, _, _ = eng.lattice_assemble(kappa.detach(), K_SAMPLE, B, Bp)
-            arr = eng.lattice_levels(vals)
-            f32 = bool(solver.mg.get("fp32"))
-            z = torch.rand((n, Bp), dtype=torch.float32 if f32 else torch.float64, device=dev)
-            x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
-            p_in = torch.rand((n, Bp), dtype=z.dtype, device=dev)       # direction stored in z's precision
-            p_out = torch.empty_like(p_in)
-            Ap = torch.empty_like(x)
-            ab = torch.rand(2, Bp, dtype=torch.float64, device=dev)
-            part = torch.empty(L.diffhe_lattice_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
-            dur = time_launch(lambda: _hip.check(L.diffhe_lattice_cg_step(
-                arr, Bv, _hip.ptr(scale), _hip.ptr(z), int(f32), _hip.ptr(p_in), _hip.ptr(p_out), _hip.ptr(x),
-                _hip.ptr(ab[0]), _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), Bp, st), "diffhe_lattice_cg_step"))
-            zb = 4.0 if f32 else 8.0
-            alg_bytes = (3 * zb + 24.0) * n * Bp  # read z, p, x; write p, Ap, x (matrix batch-shared: amortised)
-            kname = "dia_strip_kernel<M_APPLY,F_PUPD> (fused CG step: p-update + x-update + operator apply + dot)"
-            pmc_key = "F_PUPD"
-            # second kernel family: one weighted-Jacobi sweep of the V-cycle on the fine level, fp64 storage
-            rhs = torch.rand((n, Bp), dtype=torch.float64, device=dev)
-            dur_j = time_launch(lambda: _hip.check(L.diffhe_lattice_smooth(
-                arr, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), _hip.ptr(Ap), 0.8, Bp, st),
-                "diffhe_lattice_smooth"))
-            copy_dur = time_launch(lambda: Ap.copy_(x))
-            copy_gbs = 16.0 * n * Bp / copy_dur / 1e9
-            other = [{"kernel": "dia_strip_kernel<M_JACOBI> (fine-level Jacobi sweep, fp64 storage)",
-                      "achieved": round(24.0 * n * Bp / dur_j / 1e9, 1), "frac": round(24.0 * n * Bp / dur_j / 8e12, 4),
-                      "bytes_per_launch": 24.0 * n * Bp, "avg_launch_ms": round(dur_j * 1e3, 4)}]
-            try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernels, same sizes)
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    pmc = json.load(fh)
-                if pmc["pass_bytes"] == 8 * n * Bp:
-                    for k_, v_ in pmc["kernels"].items():
-                        if "dia_strip_kernel<double, float, double, 0, 2" in k_ and f32:
-                            traffic = v_["hbm_bytes_per_launch"]
-                        if "dia_strip_kernel<double, double, double, 2, 0" in k_:
-                            other[0]["traffic"] = v_["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-            del z, x, p_in, p_out, Ap, rhs, vals
-        elif roofline_ok and solver.last_info.path == "ell-pcg":
-            W = plan.W
-            vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
-            x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
-            y = torch.empty_like(x)
-            part = torch.empty(L.diffhe_grad_kappa_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
-            dur = time_launch(lambda: _hip.check(L.diffhe_ell_apply(
-                _hip.ptr(vals), _hip.ptr(plan.cols), _hip.ptr(x), _hip.ptr(y), _hip.ptr(part), n, W, Bp, Bp, st),
-                "diffhe_ell_apply"))
-            alg_bytes = (8.0 * W + 16.0) * n * Bp       # read W values + p, write Ap
-            kname = "cg_spmv_kernel"
-            del vals, x, y, part
-        if roofline_ok:
-            # `achieved` = the kernel's average duration INSIDE the solver, HIP events over the timed region (cold
-            # caches between the V-cycle and the residual update; this is the figure the rocprofv3 kernel stats of
-            # the same command show); the back-to-back launches above are reported next to it as `isolated_*`.
-            iso = alg_bytes / dur / 1e9
-            in_loop = prof_n.value > 0 and solver.last_info.path == "lattice-mgpcg"
-            dur_used = (prof_ms.value * 1e-3 / prof_n.value) if in_loop else dur
-            achieved = alg_bytes / dur_used / 1e9
-            roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur_used * 1e3, 4),
-                    "launches_timed": int(prof_n.value) if in_loop else None,
-                    "isolated_launch_ms": round(dur * 1e3, 4), "isolated_achieved": round(iso, 1),
-                    "isolated_frac": round(iso / HBM_PEAK_GBS, 4),
-                    "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None, "other_kernels": other}
-
-        # ---- CPU baseline: the oracle (port of the reference algorithm, sparse LU) -----------
-        cpu = None
-        parity = None
+        roof = roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms.value, prof_n.value)
+        if roof is not None:
+            bps = acc_bytes.value / max(args.steps, 1)
+            roof["step"] = {"bytes_per_step": bps, "launches_per_step": acc_launches.value / max(args.steps, 1),
+                            "achieved": round(bps / (ms_per_step * 1e-3) / 1e9, 1),
+                            "frac": round(bps / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "definition": "algorithmic bytes of EVERY launch of the timed steps (library accounting, "
+                                          "DESIGN.md section 4; the loss's own torch kernels excluded) / step time"}
+        cpu = parity = None
         if not args.no_cpu_baseline and world == 1:
-            from oracle import p1_oracle as orc
-            bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
-            bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
-            nodes, elements = mesh.nodes.numpy(), mesh.elements.numpy()
-            kb = float(kappa[0].detach()) if args.kappa == "sample" else kappa[0].detach().cpu().numpy()
-            tc = time.perf_counter()
-            uo, dk, _ = orc.solve_with_adjoint(nodes, elements, bn, bv, kb, np.ones(n), lambda u_: 2 * u_ / B,
-                                               sparse=True)
-            tc = time.perf_counter() - tc
-            cpu = {"value": round(1.0 / tc, 4), "unit": "solves/s", "cores": 1, "kind": "port",
-                   "sample": f"1 sample of the same workload ({N}x{N}, fwd+adjoint, scipy SuperLU), {tc:.1f} s"}
-            ug = u[0].detach().cpu().numpy()
-            parity = {"u_rel_err": float(np.max(np.abs(ug - uo)) / np.max(np.abs(uo))),
-                      "dkappa_rel_err": (float(abs(float(kappa.grad[0]) - dk.sum()) / abs(dk.sum()))
-                                         if args.kappa == "sample" else
-                                         float(np.max(np.abs(kappa.grad[0].cpu().numpy() - dk)) / np.max(np.abs(dk))))}
-
+            cpu, parity = cpu_baseline_and_parity(args, np, torch, mesh, kappa, u, B, N)
         it = np.array(timed_iters, dtype=np.float64)
+        fp32 = bool(solver.mg.get("fp32")) and lattice
         out = {
-            "metric": "FEM solves/sec (fwd+adjoint), 2D P1 Poisson 1024^2 mesh, batch=256 per GPU",
+            "metric": f"FEM solves/sec (fwd+adjoint), 2D P1 Poisson {N}^2 mesh, batch={B} per GPU",
             "value": round(value, 4), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -301,16 +240,22 @@ def main():
                                 "fp64 can attain (true residual of this workload stalls at ~3e-11 |b|)"
                                 if solver.mg.get("floor", 1) else "per sample |r| <= tol |b|"),
                        "multigrid": {k: v for k, v in solver.mg.items() if v is not None},
-                       "operator": ("K_b = kappa_b * K_1: one shared matrix + a per-sample scale; every sample is "
-                                    "solved by its own PCG (no u(1)/kappa shortcut); per-element-field figure in "
+                       "operator": ("FACTORED: K_b = kappa_b * K_1, one shared unit matrix + a per-sample scale (zero "
+                                    "matrix traffic; not bit-identical to the reference's sum_e kappa_b k0_e, 4e-13 in u "
+                                    "here); every sample is solved by its own PCG, no u(1)/kappa shortcut.  The general "
+                                    "case -- a per-element field per sample, one matrix per sample -- is "
                                     "variants.kappa_element_field") if args.kappa == "sample" else
                                    "one assembled matrix per sample and level",
-                       "precision": "fp64 arithmetic, CG vectors, residuals and dots; V-cycle (preconditioner) "
-                                    "vectors stored fp32" if solver.mg.get("fp32") else "fp64 throughout",
-                       "parallelism": f"batch-sharded x{world}"},
+                       "precision": ("fp64 arithmetic, iterate x, residual r, A p and every dot product; the CG search "
+                                     "direction p and the V-cycle (preconditioner) vectors are STORED fp32")
+                                    if fp32 else "fp64 throughout",
+                       "parallelism": f"batch-sharded x{world} (diffhe.distributed.ShardedBatchSolve, fused loss all-reduce)"},
             "solver_iters": {"fwd": int(it[:, 0].max()), "adj": int(it[:, 1].max()),
                              "max_relres_fwd": float(it[:, 2].max()), "max_relres_adj": float(it[:, 3].max()),
                              "not_converged": int(it[:, 4].max())},
+            "headline_note": (None if variant is None else
+                              f"factored scalar-kappa operator: {round(value, 1)} solves/s; per-element kappa field per "
+                              f"sample (general case): {variant['kappa_element_field']['value_per_gpu']} solves/s"),
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity, "variants": variant,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
         }
@@ -318,6 +263,215 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, dist, torch):
+    """Launch-path rehearsal without a GPU: rendezvous over gloo, the barrier-bracketed timed region, the
+    max-over-ranks reduction and rank 0's JSON line -- with no solve and therefore no value."""
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))           # ranks finish at different times: the MAX must win
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if rank == 0:
+        print(json.dumps({"metric": f"FEM solves/sec (fwd+adjoint), 2D P1 Poisson {args.mesh}^2 mesh, "
+                                    f"batch={args.batch} per GPU", "value": None, "unit": "solves/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True,
+                          "scaling": "weak", "dry_run": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, prof_n):
+    """Roofline entry of the dominant kernel: algorithmic bytes per launch / its average duration in the solver."""
+    from diffhe.plan import padded_batch
+    Bp = padded_batch(B)
+    path = solver.last_info.path
+    # the fused CG step (and its roofline entry) exists for wave-sized batches on strip-sized meshes only
+    ok = (path == "lattice-mgpcg" and args.kappa == "sample" and Bp >= 64 and N >= 191) or path == "ell-pcg"
+    if not ok:
+        return None
+    st = torch.cuda.current_stream(dev).cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def time_launch(launch):
+        for _ in range(3):
+            launch()
+        e0.record()
+        for _ in range(args.kernel_reps):
+            launch()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / args.kernel_reps
+
+    other, traffic, traffic_src, copy_gbs = None, None, None, None
+    if path == "lattice-mgpcg":
+        # The kernel with the largest share of the step (profiles/*_kernel_stats.csv) is the fused CG step
+        # dia_strip_kernel<M_APPLY, F_PUPD> (p = z + beta p, x += alpha p_old, Ap = A p, p.Ap); it is also timed
+        # alone on the operator this workload assembles (shared unit matrix + kappa_b scale).
+        from diffhe.solver import _Engine, K_SAMPLE
+        eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
+        vals, Bv, scale, _, _ = eng.lattice_assemble(kappa.detach(), K_SAMPLE, B, Bp)
+        arr = eng.lattice_levels(vals)
+        f32 = bool(solver.mg.get("fp32"))
+        z = torch.rand((n, Bp), dtype=torch.float32 if f32 else torch.float64, device=dev)
+        x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+        p_in = torch.rand((n, Bp), dtype=z.dtype, device=dev)       # direction stored in z's precision
+        p_out = torch.empty_like(p_in)
+        Ap = torch.empty_like(x)
+        ab = torch.rand(2, Bp, dtype=torch.float64, device=dev)
+        part = torch.empty(L.diffhe_lattice_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
+        dur = time_launch(lambda: _hip.check(L.diffhe_lattice_cg_step(
+            arr, Bv, _hip.ptr(scale), _hip.ptr(z), int(f32), _hip.ptr(p_in), _hip.ptr(p_out), _hip.ptr(x),
+            _hip.ptr(ab[0]), _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), Bp, st), "diffhe_lattice_cg_step"))
+        zb = 4.0 if f32 else 8.0
+        alg_bytes = (3 * zb + 24.0) * n * Bp  # read z, p, x; write p, Ap, x (matrix batch-shared: amortised)
+        kname = "dia_strip_kernel<M_APPLY,F_PUPD> (fused CG step: p-update + x-update + operator apply + dot)"
+        # second kernel family: one weighted-Jacobi sweep of the V-cycle on the fine level, fp64 storage
+        rhs = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+        dur_j = time_launch(lambda: _hip.check(L.diffhe_lattice_smooth(
+            arr, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), _hip.ptr(Ap), 0.8, Bp, st),
+            "diffhe_lattice_smooth"))
+        copy_dur = time_launch(lambda: Ap.copy_(x))
+        copy_gbs = 16.0 * n * Bp / copy_dur / 1e9
+        other = [{"kernel": "dia_strip_kernel<M_JACOBI> (fine-level Jacobi sweep, fp64 storage)",
+                  "achieved": round(24.0 * n * Bp / dur_j / 1e9, 1), "frac": round(24.0 * n * Bp / dur_j / 8e12, 4),
+                  "bytes_per_launch": 24.0 * n * Bp, "avg_launch_ms": round(dur_j * 1e3, 4)}]
+        # HBM bytes per launch: NOT measured in this run -- read from the PMC passes committed under profiles/
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernels, same sizes; tools/pmc_reduce.py)
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh)
+            except Exception:
+                continue
+            if pmc.get("pass_bytes") != 8 * n * Bp:
+                continue
+            for k_, v_ in pmc["kernels"].items():
+                if "dia_strip_kernel<double, float, double, 0, 2" in k_ and f32:
+                    traffic, traffic_src = v_["hbm_bytes_per_launch"], f"profiles/{name} (committed PMC passes, not this run)"
+                if "dia_strip_kernel<double, double, double, 2, 0" in k_:
+                    other[0]["traffic"] = v_["hbm_bytes_per_launch"]
+            if traffic is not None:
+                break
+        del z, x, p_in, p_out, Ap, rhs, vals
+    else:
+        W = plan.W
+        vals = torch.rand((W, n, Bp), dtype=torch.float64, device=dev)
+        x = torch.rand((n, Bp), dtype=torch.float64, device=dev)
+        y = torch.empty_like(x)
+        part = torch.empty(L.diffhe_grad_kappa_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
+        dur = time_launch(lambda: _hip.check(L.diffhe_ell_apply(
+            _hip.ptr(vals), _hip.ptr(plan.cols), _hip.ptr(x), _hip.ptr(y), _hip.ptr(part), n, W, Bp, Bp, st),
+            "diffhe_ell_apply"))
+        alg_bytes = (8.0 * W + 16.0) * n * Bp       # read W values + p, write Ap (DESIGN.md)
+        kname = "cg_spmv_kernel"
+        del vals, x, y, part
+    # `achieved` = the kernel's average duration INSIDE the solver, HIP events over the timed region (cold
+    # caches between the V-cycle and the residual update; this is the figure the rocprofv3 kernel stats of
+    # the same command show); the back-to-back launches above are reported next to it as `isolated_*`.
+    iso = alg_bytes / dur / 1e9
+    in_loop = prof_n > 0 and path == "lattice-mgpcg"
+    dur_used = (prof_ms * 1e-3 / prof_n) if in_loop else dur
+    achieved = alg_bytes / dur_used / 1e9
+    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": round(dur_used * 1e3, 4),
+            "launches_timed": int(prof_n) if in_loop else None,
+            "launches_timed_note": "full-work launches only: the first step of each solve (p = z, 16 B/node) is left out",
+            "isolated_launch_ms": round(dur * 1e3, 4), "isolated_achieved": round(iso, 1),
+            "isolated_frac": round(iso / HBM_PEAK_GBS, 4),
+            "stream_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+            "stream_ceiling_note": "profiles/r02_stream_bench.txt: 4.7-5.6 TB/s for 1R1W..2R2W mixes, 6.3-6.5 read-only",
+            "other_kernels": other}
+
+
+def _oracle_sample(job):
+    """Pool worker of the sparse CPU baseline: one fwd + adjoint of the oracle (scipy SuperLU, 1 thread)."""
+    nodes, elements, bn, bv, kb, B, n = job
+    import numpy as np
+    from oracle import p1_oracle as orc
+    t = time.perf_counter()
+    uo, dk, _ = orc.solve_with_adjoint(nodes, elements, bn, bv, kb, np.ones(n), lambda u_: 2 * u_ / B, sparse=True)
+    return uo, (dk.sum() if np.ndim(kb) == 0 else dk), time.perf_counter() - t
+
+
+def cpu_baseline_and_parity(args, np, torch, mesh, kappa, u, B, N):
+    """CPU restatements of the reference path on this box's host cores, and -- from the same oracle
+    solves -- parity of the GPU result on several samples of the batch including the first and the last."""
+    import multiprocessing as mp
+    from oracle import p1_oracle as orc
+    from oracle import torch_dense as td
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = mesh.n_nodes
+    bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
+    bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
+    nodes, elements = mesh.nodes.numpy(), mesh.elements.numpy()
+
+    # (ii) sparse flavour at the bench size: the oracle (reference-order assembly, SuperLU fwd + adjoint), one
+    # sample per worker process on `workers` cores at once (SuperLU itself is single-threaded)
+    workers = max(1, min(cores, 16, B))
+    idx = sorted({int(round(i * (B - 1) / max(workers - 1, 1))) for i in range(workers)})   # first ... last
+    kap = kappa.detach().cpu().numpy()
+    jobs = [(nodes, elements, bn, bv, (float(kap[b]) if args.kappa == "sample" else kap[b]), B, n) for b in idx]
+    tc = time.perf_counter()
+    if len(jobs) > 1:
+        with mp.get_context("spawn").Pool(len(jobs)) as pool:
+            res = pool.map(_oracle_sample, jobs)
+    else:
+        res = [_oracle_sample(jobs[0])]
+    tc = time.perf_counter() - tc
+    single = float(np.mean([r[2] for r in res]))
+    ue, ge = 0.0, 0.0
+    ug = u.detach()
+    kg = kappa.grad.detach()
+    for b, (uo, dk, _) in zip(idx, res):
+        ue = max(ue, float(np.max(np.abs(ug[b].cpu().numpy() - uo)) / np.max(np.abs(uo))))
+        if args.kappa == "sample":
+            ge = max(ge, float(abs(float(kg[b]) - dk) / abs(dk)))
+        else:
+            ge = max(ge, float(np.max(np.abs(kg[b].cpu().numpy() - dk)) / np.max(np.abs(dk))))
+    parity = {"u_rel_err": ue, "dkappa_rel_err": ge, "samples_checked": idx,
+              "against": "oracle/p1_oracle.py (reference-order assembly + SuperLU), max over the checked samples"}
+
+    # (i) "reference-faithful dense" flavour: vectorised assembly -> dense torch.linalg.solve -> autograd backward
+    # (oracle/torch_dense.py), all cores through torch's intra-op threads, at the sizes a dense matrix reaches
+    table = []
+    for label, m_ in (("C1: 1D 20 elements", orc.mesh_line(20)), ("1D 1000 elements", orc.mesh_line(1000)),
+                      ("2D 32x32", orc.mesh_rectangle(32, 32)), ("2D 64x64", orc.mesh_rectangle(64, 64))):
+        nn_ = len(m_[0])
+        td.differentiable_solve(*m_, 1.3, np.ones(nn_))                      # warm-up (LAPACK first call)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 0.5 and reps < 200):
+            td.differentiable_solve(*m_, 1.3, np.ones(nn_))
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        table.append({"config": label, "flavour": "dense torch.linalg.solve + autograd (vectorised assembly)",
+                      "solves_per_s": round(1.0 / dt, 3), "ms_per_solve": round(1e3 * dt, 3), "threads": cores})
+    table.append({"config": f"bench size: 2D {N}x{N}", "flavour": "sparse: reference-order assembly + SuperLU fwd + adjoint",
+                  "solves_per_s": round(len(jobs) / tc, 4), "ms_per_solve": round(1e3 * tc / len(jobs), 1),
+                  "threads": len(jobs), "single_sample_s": round(single, 2)})
+    cpu = {"value": round(len(jobs) / tc, 4), "unit": "solves/s", "cores": len(jobs), "kind": "port",
+           "host_cores_available": cores,
+           "sample": f"{len(jobs)} samples of the same workload ({N}x{N}, fwd+adjoint, oracle: scipy SuperLU), one per "
+                     f"process on {len(jobs)} cores at once, {tc:.1f} s wall ({single:.1f} s per sample)",
+           "table": table,
+           "note": "baseline only; the reference's own Python loops cannot run this size at all (dense K = 8.8 TB)"}
+    return cpu, parity
 
 
 if __name__ == "__main__":

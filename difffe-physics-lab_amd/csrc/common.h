@@ -11,6 +11,11 @@ constexpr int kWave = 64;
 
 void set_last_error(hipError_t e);
 
+// Algorithmic-byte accounting (diffhe_traffic_account): every launch on the solve path adds the unique bytes it
+// must read + write once (batch-shared data counts 0).  Process-wide: the adjoint solve runs on
+// autograd's thread.  bench.py divides the total of a step by the step's duration for the step-level roofline.
+void account(double bytes);
+
 // Post-launch check: records the HIP error text and maps to DIFFHE_E_LAUNCH.
 inline int check_launch() {
   hipError_t e = hipGetLastError();

@@ -798,6 +798,7 @@ extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa
   if (!local || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
   if (is_bc && !g) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  diffhe::account(8.0 * Bv * ((double)W * n + (lift ? n : 0) + ((kappa && kappa_se) ? m : 0)));  // stored values, lift, kappa field
   hipLaunchKernelGGL(assemble_rows_kernel<false>, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local,
                      (const double*)nullptr, kappa, kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g,
                      vals, lift, n, m, W, Bv);
@@ -812,6 +813,7 @@ extern "C" int diffhe_ell_assemble_rows_ref(const double* tnum, const double* de
   if (!tnum || !den || !ent_ptr || !contrib || !cols || !vals || n < 1 || m < 1 || W < 1) return DIFFHE_E_BADARG;
   if (is_bc && !g) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  diffhe::account(8.0 * Bv * ((double)W * n + (lift ? n : 0) + ((kappa && kappa_se) ? m : 0)));
   hipLaunchKernelGGL(assemble_rows_kernel<true>, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, tnum, den,
                      kappa, kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g, vals, lift, n, m, W, Bv);
   return diffhe::check_launch();
@@ -846,6 +848,7 @@ extern "C" int diffhe_ell_spmv_shared(const double* vals, const int* cols, const
   if (!vals || !cols || !x || !y || n < 1 || W < 1) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
+  diffhe::account(16.0 * n * Bp);
   hipLaunchKernelGGL(spmv_shared_kernel, diffhe::node_grid(n, Bp), dim3(256), 0, (hipStream_t)stream, vals, cols, x,
                      sub, sub_B, sub_scale, is_bc, y, n, W, Bp);
   return diffhe::check_launch();
@@ -1059,6 +1062,7 @@ extern "C" int diffhe_p1_grad_kappa(const int* elems, const double* k0, const do
   if (!elems || !k0 || !lam || !u || !dk_part || !dk_sum || (npe != 2 && npe != 3) || m < 1) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   const dim3 grid = diffhe::node_grid(m, Bp);
+  diffhe::account(8.0 * Bp * (2.0 * m * (npe == 3 ? 0.5 : 1.0) + (dk_e ? m : 0)));  // lambda and u once per node, dk per element
   hipLaunchKernelGGL(grad_kappa_kernel, grid, dim3(256), 0, (hipStream_t)stream, elems, k0, lam, u, g, npe, m, Bp,
                      dk_e, dk_part);
   hipLaunchKernelGGL(sum_partials_kernel, dim3((Bp + 63) / 64), dim3(256), 0, (hipStream_t)stream,
@@ -1070,6 +1074,7 @@ extern "C" int diffhe_to_node_major(const double* src, long long ld, const unsig
                                     int B, int Bp, void* stream) {
   if (!src || !dst || n < 1 || B < 1 || Bp < B) return DIFFHE_E_BADARG;
   dim3 grid((n + kT - 1) / kT, (Bp + kT - 1) / kT);
+  diffhe::account(8.0 * n * ((ld ? (double)B : 1.0) + Bp));
   hipLaunchKernelGGL(to_node_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, zero_mask, dst, n, B, Bp);
   return diffhe::check_launch();
 }
@@ -1078,6 +1083,7 @@ extern "C" int diffhe_to_sample_major(const double* src, const double* add, doub
                                       int Bp, void* stream) {
   if (!src || !dst || n < 1 || B < 1 || Bp < B) return DIFFHE_E_BADARG;
   dim3 grid((n + kT - 1) / kT, (Bp + kT - 1) / kT);
+  diffhe::account(8.0 * n * ((double)B + Bp));
   hipLaunchKernelGGL(to_sample_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, ld, n, B, Bp);
   return diffhe::check_launch();
 }

@@ -508,11 +508,21 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
                   double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st,
                   const Extra& ex = Extra{}) {
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
+  // per-sample matrices inside the fp32 V-cycle read the fp32 copy of the coefficients
+  const bool m32 = (sizeof(TV) == 4) && Bv != 1 && L.v32 != nullptr;
+  {  // algorithmic bytes per (node, sample) of this launch (diffhe_traffic_account)
+    const double tv = sizeof(TV), ta = sizeof(TA);
+    double bpn;
+    if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * tv + (FUSE == F_PROLONG ? 0.25 * tv : 0.0);
+    else if (MODE == M_RESID) bpn = 2.0 * tv + (FUSE == F_RESTRICT ? 0.25 * tv : (out ? tv : 0.0) + (ex.r32 ? 4.0 : 0.0));
+    else if (FUSE == F_PUPD) bpn = ex.first ? 2.0 * ta + 8.0 : 3.0 * ta + 24.0;
+    else bpn = tv + (out ? tv : 0.0) + (ex.dotv ? 8.0 : 0.0);
+    if (Bv != 1) bpn += L.nd * (m32 ? 4.0 : 8.0);
+    diffhe::account(bpn * (double)L.n * Bp);
+  }
 #define STRIP(ND_, SH_, TM_)                                                                                       \
   hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW>), grid, dim3(256), 0, st, L,   \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
-  // per-sample matrices inside the fp32 V-cycle read the fp32 copy of the coefficients
-  const bool m32 = (sizeof(TV) == 4) && Bv != 1 && L.v32 != nullptr;
   if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true, double); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
   } else {
@@ -903,7 +913,14 @@ struct Hier {
 
 inline dim3 lgrid(int n, int Bp) { return node_grid(n, Bp, 2048); }  // <= kPartBlocks partial rows
 
-#define LAUNCH(kernel, n, ...) hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__)
+// bpn = algorithmic bytes per (node, sample) of the launch, for diffhe_traffic_account
+#define LAUNCH(bpn, kernel, n, ...)                                                  \
+  do {                                                                               \
+    diffhe::account((double)(bpn) * (double)(n) * H.Bp);                             \
+    hipLaunchKernelGGL(kernel, lgrid((n), H.Bp), dim3(256), 0, st, __VA_ARGS__);     \
+  } while (0)
+// per-sample matrices: bytes of the nd stored diagonals (fp64) per node; a batch-shared matrix is amortised to 0
+#define MATB(L) (H.Bv == 1 ? 0.0 : 8.0 * (L).nd)
 
 // ---- operator dispatch: strip kernels on big levels, simple kernels on small ones ----------------
 // Each returns the number of partial blocks it wrote (when `part` != NULL).  TV is the storage
@@ -919,7 +936,7 @@ int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, doub
                                                                    H.Bp, g, st);
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, xin, xout, omega, part, H.Bp);
+  LAUNCH((xin ? 3 : 2) * sizeof(TV) + MATB(L), dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, xin, xout, omega, part, H.Bp);
   return lgrid(L.n, H.Bp).x;
 }
 
@@ -935,8 +952,8 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
     *result = xa;
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, xa, w0, (double*)nullptr, H.Bp);
-  LAUNCH(dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, xb, w1, part, H.Bp);
+  LAUNCH(2 * sizeof(TV) + MATB(L) / L.nd, dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, xa, w0, (double*)nullptr, H.Bp);
+  LAUNCH(3 * sizeof(TV) + MATB(L), dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, xb, w1, part, H.Bp);
   *result = xb;
   return lgrid(L.n, H.Bp).x;
 }
@@ -949,7 +966,7 @@ int op_residual(const Hier& H, int l, const TV* rhs, const TV* x, TV* res, doubl
     launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st);
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
+  LAUNCH((res ? 3 : 2) * sizeof(TV) + MATB(L), dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
   return lgrid(L.n, H.Bp).x;
 }
 
@@ -960,7 +977,7 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
     launch_strip<double, M_APPLY, false>(L, H.Bv, H.scale, x, (const double*)nullptr, y, 0.0, 0.0, part, H.Bp, g, st);
     return g.ncb * g.nrc;
   }
-  LAUNCH(dia_apply_dot_kernel, L.n, L, H.Bv, H.scale, x, y, part, H.Bp);
+  LAUNCH(16.0 + MATB(L), dia_apply_dot_kernel, L.n, L, H.Bv, H.scale, x, y, part, H.Bp);
   return lgrid(L.n, H.Bp).x;
 }
 
@@ -983,11 +1000,11 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   TV* xb = (TV*)H.xb[l];
   TV* d = (TV*)H.res[l];  // the coarsest level never restricts: its residual buffer holds d
   double rho = 1.0 / sigma;
-  LAUNCH(dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, (const TV*)nullptr, xa, d, 0.0,
+  LAUNCH(3 * sizeof(TV) + MATB(L) / L.nd, dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)nullptr, (const TV*)nullptr, xa, d, 0.0,
          1.0 / theta, (deg == 1) ? part : (double*)nullptr, H.Bp);
   for (int k = 1; k < deg; ++k) {
     const double rho_new = 1.0 / (2.0 * sigma - rho);
-    LAUNCH(dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, (const TV*)d, xb, d, rho_new * rho,
+    LAUNCH(5 * sizeof(TV) + MATB(L), dia_cheby_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, (const TV*)xa, (const TV*)d, xb, d, rho_new * rho,
            2.0 * rho_new / delta, (k == deg - 1) ? part : (double*)nullptr, H.Bp);
     rho = rho_new;
     TV* t = xa; xa = xb; xb = t;
@@ -1055,7 +1072,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
                                                                        (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
       } else {
         op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
-        LAUNCH(mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
+        LAUNCH(((double)L.n / C.n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
       }
       rhs[l + 1] = (const TV*)H.rhs[l + 1];
     }
@@ -1078,7 +1095,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       TV* t = a; a = b2; b2 = t;
       s0 = 1;
     } else {
-      LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
+      LAUNCH((2.0 + (double)C.n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
     }
     for (int s = s0; s < H.nu; ++s) {
       const bool lastsweep = (l == l0 && s == H.nu - 1);
@@ -1100,7 +1117,7 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
   const TV* bl[kMaxLevels];
   bl[0] = b0;
   for (int l = 0; l < last; ++l) {
-    LAUNCH(mg_restrict_kernel<TV>, H.lev[l + 1].n, H.lev[l], H.lev[l + 1], bl[l], (TV*)H.bF[l + 1], H.Bp);
+    LAUNCH(((double)H.lev[l].n / H.lev[l + 1].n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, H.lev[l + 1].n, H.lev[l], H.lev[l + 1], bl[l], (TV*)H.bF[l + 1], H.Bp);
     bl[l + 1] = (const TV*)H.bF[l + 1];
   }
   {  // coarsest level: the V-cycle from `last` is n_coarse Jacobi sweeps
@@ -1111,12 +1128,12 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
   for (int l = last - 1; l >= 0; --l) {
     const Level& L = H.lev[l];
     TV* x = (TV*)H.xF[l];
-    LAUNCH(mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], (const TV*)H.xF[l + 1], x, H.Bp, 1);
+    LAUNCH((1.0 + (double)H.lev[l + 1].n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], (const TV*)H.xF[l + 1], x, H.Bp, 1);
     const int cycles = (l == 0) ? 1 : H.fmg_coarse_cycles;  // extra cycles on the cheap coarse levels
     for (int c = 0; c < cycles; ++c) {
       op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
       TV* e = vcycle<TV>(H, (const TV*)H.rhs[l], nullptr, nullptr, st, l);
-      LAUNCH(mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
+      LAUNCH(3 * sizeof(TV), mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
     }
   }
   return (TV*)H.xF[0];
@@ -1274,9 +1291,9 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 
   int nbz = 0, nba = 0;
   const bool light_init = use_fmg && f32;  // the start overwrites x and r; it reads b through r32
-  LAUNCH(pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
+  LAUNCH(light_init ? 8.0 : 24.0, pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
-  if (f32) LAUNCH(pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
+  if (f32) LAUNCH(12.0, pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
   // Fused loop (fine level runs the strip kernels): per iteration
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
@@ -1307,8 +1324,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       nba = g0.ncb * g0.nrc;
       if (g_prof.on && !first) (void)hipEventRecord(g_prof.e1, st);
     } else {
-      if (f32) LAUNCH(pcg_update_p_kernel<float>, n, (const float*)z, (const double*)S.beta, p, first, n, Bp);
-      else LAUNCH(pcg_update_p_kernel<double>, n, (const double*)z, (const double*)S.beta, p, first, n, Bp);
+      if (f32) LAUNCH(first ? 12.0 : 20.0, pcg_update_p_kernel<float>, n, (const float*)z, (const double*)S.beta, p, first, n, Bp);
+      else LAUNCH(first ? 16.0 : 24.0, pcg_update_p_kernel<double>, n, (const double*)z, (const double*)S.beta, p, first, n, Bp);
       nba = op_apply_dot(H, p, Ap, partA, st);
     }
   };
@@ -1316,11 +1333,11 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     if (f32) {
       const float* x0 = fmg_start<float>(H, (const float*)r32, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x, use_floor ? partA : (double*)nullptr, n, Bp);
+      LAUNCH(12.0, pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x, use_floor ? partA : (double*)nullptr, n, Bp);
     } else {
       const double* x0 = fmg_start<double>(H, b, st);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x, use_floor ? partA : (double*)nullptr, n, Bp);
+      LAUNCH(16.0, pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x, use_floor ? partA : (double*)nullptr, n, Bp);
     }
     if (use_floor) SCALAR(S_FLOOR, partA, nblk);
     const StripGeom gr = strip_geom(L0, Bp);
@@ -1331,7 +1348,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, nullptr, Bp, gr, st, ex);
     } else {
       op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
-      if (f32) LAUNCH(pcg_cvt_kernel, n, (const double*)r, (const double*)S.rs, r32, n, Bp);
+      if (f32) LAUNCH(12.0, pcg_cvt_kernel, n, (const double*)r, (const double*)S.rs, r32, n, Bp);
     }
   }
   precondition(1);
@@ -1342,7 +1359,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   while (it < max_iter) {
     apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
-    LAUNCH(pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
+    LAUNCH(24.0 + (r32 ? 4.0 : 0.0) + (fused ? 0.0 : 24.0), pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
            r, r32, (const double*)S.rs, partA, n, Bp);
     SCALAR(S_CONV, partA, nblk);
     ++it;
@@ -1364,8 +1381,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     if (n_active == 0) break;
   }
   if (fused && it > 0) {
-    if (f32) LAUNCH(pcg_axpy_kernel<float>, n, (const double*)S.alpha, (const float*)(const void*)p, x, n, Bp);
-    else LAUNCH(pcg_axpy_kernel<double>, n, (const double*)S.alpha, (const double*)p, x, n, Bp);
+    if (f32) LAUNCH(20.0, pcg_axpy_kernel<float>, n, (const double*)S.alpha, (const float*)(const void*)p, x, n, Bp);
+    else LAUNCH(24.0, pcg_axpy_kernel<double>, n, (const double*)S.alpha, (const double*)p, x, n, Bp);
   }
   nba = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
   SCALAR(S_RELRES, partA, nba);
@@ -1467,6 +1484,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
                                          (hipStream_t)stream, ex);
     return diffhe::check_launch();
   }
+  diffhe::account((16.0 + (sub && sub_B != 1 ? 8.0 : 0.0)) * (double)L.n * Bp);
   hipLaunchKernelGGL(dia_shared_apply_kernel, lgrid(L.n, Bp), dim3(256), 0, (hipStream_t)stream, L, x, sub, sub_B,
                      sub_scale, mask, y, Bp);
   return diffhe::check_launch();
@@ -1487,6 +1505,7 @@ extern "C" int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* k
   if (!kappa_fine || !kappa_coarse || nx_coarse < 1 || ny_coarse < 1) return DIFFHE_E_BADARG;
   if ((sx != 1 && sx != 2) || (sy != 1 && sy != 2) || (sx == 1 && sy == 1)) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  diffhe::account(8.0 * Bv * (2.0 * nx_coarse * ny_coarse) * (1.0 + sx * sy));
   hipLaunchKernelGGL(mg_restrict_kappa_kernel, node_grid(2 * nx_coarse * ny_coarse, Bv), dim3(256), 0,
                      (hipStream_t)stream, kappa_fine, kappa_coarse, nx_coarse, ny_coarse, sx, sy, Bv);
   return diffhe::check_launch();

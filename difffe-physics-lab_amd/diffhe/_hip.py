@@ -37,6 +37,7 @@ SIGNATURES = {
     "diffhe_abi_version": (_I, []),
     "diffhe_status_string": (C.c_char_p, [_I]),
     "diffhe_last_hip_error": (C.c_char_p, []),
+    "diffhe_traffic_account": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_chain1d_stage_doubles": (_L, [_I, _I, _I, _I]),
     "diffhe_chain1d_solve": (_I, [_P, _P, _L, _L, _P, _L, _P, _I, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "diffhe_chain1d_adjoint": (_I, [_P, _P, _L, _L, _P, _L, _P, _L, _P, _I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P,

@@ -24,13 +24,32 @@ def shard_range(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# messages from this size on are reduced as reduce-scatter + all-gather (every rank sums 1/world of the buffer and
+# every pair of ranks exchanges 1/world of it: all 7 xGMI links of a GPU carry traffic at once), below it as one
+# latency-bound all-reduce
+_TWO_PHASE_BYTES = 1 << 20
+
+
 def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None) -> None:
-    """In-place SUM all-reduce of several tensors as ONE message (loss scalar + gradient):
-    latency-bound for the 8-16 B case, one reduce-scatter/all-gather for the MB case."""
+    """In-place SUM all-reduce of several tensors as ONE message (loss scalar + gradient).
+    8-16 B (scalar loss, shared scalar kappa): a single all-reduce.  MB-sized (a shared per-element kappa gradient,
+    16.8 MB at 1024^2): reduce-scatter + all-gather on the RCCL backend; gloo (CPU tests) has no reduce-scatter and
+    keeps the single all-reduce -- same result either way (SUM over ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    world = dist.get_world_size(group)
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.numel() * flat.element_size() >= _TWO_PHASE_BYTES and dist.get_backend(group) == "nccl":
+        n = flat.numel()
+        per = (n + world - 1) // world
+        padded = torch.zeros(per * world, dtype=flat.dtype, device=flat.device)
+        padded[:n] = flat
+        mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(padded, mine, group=group)
+        flat = padded[:n]
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].reshape(t.shape))
@@ -64,8 +83,16 @@ class ShardedBatchSolve:
         B = f_global.shape[0]
         lo, hi = shard_range(B, self.rank, self.world)
         kappa = shared_kappa if shared_kappa is not None else sample_kappa[lo:hi]
-        u = self.local_solve(kappa, f_global[lo:hi])
-        loss_local = loss_fn(u, lo, hi) / B
+        return self.step_local(f_global[lo:hi], B, lambda u: loss_fn(u, lo, hi), kappa,
+                               shared_kappa if shared_kappa is not None else None)
+
+    def step_local(self, f_local: torch.Tensor, B_global: int, loss_sum_fn: Callable[[torch.Tensor], torch.Tensor],
+                   kappa: torch.Tensor, shared_kappa: Optional[torch.Tensor] = None):
+        """The same step when every rank already holds (only) its shard -- the layout of `bench.py`, where
+        the global batch (2048 x 8.4 MB at BASELINE config 4) is never materialised on one GPU.
+        loss_sum_fn(u_local) = SUM over this shard's samples.  Returns (loss_global, u_local)."""
+        u = self.local_solve(kappa, f_local)
+        loss_local = loss_sum_fn(u) / B_global
         loss_local.backward()
         loss = loss_local.detach().clone().reshape(1)
         bufs = [loss]

@@ -10,10 +10,16 @@ Differences that do not change results: the FEM target is cached while
 system on every call (loss.py:81-82) -- and 2D meshes work (the reference's
 `nodes.squeeze(1)` makes 2D fail): for dim 2 the forcing
 callable receives the (n,2) coordinates and returns (n,) values.
+
+RHS ensembles (the reference loops `PhysicsLoss` call by call, one identical-matrix solve
+each, loss.py:78-83): `forcing_fns=[f_1, ..., f_B]`, or a `forcing_fn` that returns (B, n), makes the FEM target
+ONE batched solve of B right-hand sides (cached like the single target).  `forward` then returns the mean of the
+B per-member losses -- exactly `mse_loss` over the (B, n) target -- and `member_losses` the B values a loop of
+reference calls would produce (fixture G12).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -23,11 +29,21 @@ from .solver import DifferentiableFESolver
 
 
 class PhysicsLoss(nn.Module):
-    def __init__(self, mesh: FEMesh, forcing_fn: Callable[[torch.Tensor], torch.Tensor],
-                 mode: str = "fem_match", solver: Optional[DifferentiableFESolver] = None):
+    def __init__(self, mesh: FEMesh, forcing_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 mode: str = "fem_match", solver: Optional[DifferentiableFESolver] = None, *,
+                 forcing_fns: Optional[Sequence[Callable[[torch.Tensor], torch.Tensor]]] = None):
         super().__init__()
         if mode not in ("fem_match", "variational"):
             raise ValueError(f"Unknown mode: {mode!r}")
+        if (forcing_fn is None) == (forcing_fns is None):
+            raise ValueError("give exactly one of forcing_fn and forcing_fns")
+        if forcing_fns is not None:
+            if mode != "fem_match":
+                raise ValueError("forcing_fns (an ensemble of right-hand sides) needs mode='fem_match'")
+            fns = tuple(forcing_fns)
+            if not fns:
+                raise ValueError("forcing_fns is empty")
+            forcing_fn = lambda pts: torch.stack([fn(pts) for fn in fns])    # noqa: E731  (B, n)
         self.mesh = mesh
         self.forcing_fn = forcing_fn
         self.mode = mode
@@ -57,7 +73,20 @@ class PhysicsLoss(nn.Module):
 
     def _fem_match_loss(self, u_pred: torch.Tensor) -> torch.Tensor:
         u_fem = self.fem_target().to(u_pred.device)
+        if u_fem.dim() == 2 and u_pred.dim() == 1:      # one prediction against every member of the ensemble
+            u_pred = u_pred.unsqueeze(0).expand_as(u_fem)
         return nn.functional.mse_loss(u_pred.double(), u_fem.double())
+
+    def member_losses(self, u_pred: torch.Tensor) -> torch.Tensor:
+        """(B,) fem_match losses, one per member of the ensemble -- what B separate reference
+        `PhysicsLoss(mesh, f_b)(u_pred)` calls return (loss.py:78-83); their mean is `forward(u_pred)`."""
+        u_fem = self.fem_target().to(u_pred.device).double()
+        if u_fem.dim() == 1:
+            u_fem = u_fem.unsqueeze(0)
+        up = u_pred.double()
+        if up.dim() == 1:
+            up = up.unsqueeze(0)
+        return ((up - u_fem) ** 2).mean(dim=1)
 
     def _variational_loss(self, u_pred: torch.Tensor) -> torch.Tensor:
         x = self.mesh.nodes.squeeze(1)

@@ -39,6 +39,13 @@ const char* diffhe_status_string(int status);
 /* hipGetLastError()-style text of the last DIFFHE_E_LAUNCH on this thread. */
 const char* diffhe_last_hip_error(void);
 
+/* Algorithmic-byte accounting of the solve path.  Every kernel launch of the lattice path and of the shared
+ * set-up / layout kernels adds the unique bytes it must read + write once (batch-shared
+ * data counts 0; per-sample matrices count their stored diagonals) to a process-wide counter.
+ * Returns the totals since the last reset; reset != 0 clears them.  bench.py divides the bytes of the timed
+ * steps by their duration: the step-level fraction of the HBM roofline. */
+int diffhe_traffic_account(int reset, double* bytes_host, long long* launches_host);
+
 /* ------------------------------------------------------------------------------
  * 1D chain path (elements[e] = (e, e+1)).  Fused assemble + solve; K is never
  * materialised.  The P1 stiffness of a chain is a weighted path-graph Laplacian:

@@ -4,8 +4,11 @@ one fused SUM all-reduce of [loss, shared-kappa gradient], no collective on the 
 The per-rank solve is injected: on a CPU box the HIP solve cannot run, so the ORACLE stands in
 as the local solve (allowed for tests) -- what is exercised is the sharding / reduction logic,
 whose result must equal the single-process loop of reference solves (fixture G9 semantics)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -101,3 +104,112 @@ def test_single_process_is_a_noop_for_collectives():
     k = torch.tensor(2.0, requires_grad=True)
     loss, u = drv.step(torch.ones(4, 3), lambda u, lo, hi: u.sum(), shared_kappa=k)
     assert float(loss) == 6.0 and float(k.grad) == 3.0
+
+
+# --- bench.py's own multi-rank launch path -----------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two fresh rank processes, they rendezvous
+    (gloo, 127.0.0.1), time the steps between barriers, reduce the MAX over ranks and rank 0 prints n_gpus = 2.
+    --dry-run: no GPU on this box, so no solve and no value -- the launch path is what is under test."""
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+                          "--dry-run"], capture_output=True, text=True, timeout=600, env=clean)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["dry_run"] is True and res["value"] is None
+    # rank r sleeps 10 (1 + r) ms per step: the reported time is the slower rank's (MAX over ranks)
+    assert res["ms_per_step"] >= 19.0
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_a_launcher_takes_the_ranks_from_the_environment():
+    """The driver's form: torch.distributed.run sets RANK / WORLD_SIZE and passes --gpus N to every rank."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                                       "--dry-run"], stdout=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    js = [[ln for ln in o.splitlines() if ln.startswith("{")] for o in outs]     # gloo prints a banner line of its own
+    assert len(js[0]) == 1 and json.loads(js[0][0])["n_gpus"] == 2 and js[1] == []
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "MASTER_PORT")}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                         capture_output=True, text=True, env=dict(clean, WORLD_SIZE="2"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+# --- the HIP path under torch.distributed (GPU box) ------------------------------------------------------------
+def _hip_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks on cuda:0: RCCL needs one GPU each
+    try:
+        from diffhe import FEMesh, DifferentiableFESolver
+        g = golden("g9_batch_2d_8")
+        bc = {int(k): float(v) for k, v in zip(g["bc_nodes"], g["bc_vals"])}
+        mesh = FEMesh(nodes=torch.from_numpy(g["nodes"]), elements=torch.from_numpy(g["elements"]), dirichlet_nodes=bc)
+        f = torch.from_numpy(g["f"]).cuda()
+        kappa = torch.tensor(float(g["kappa"][0]), dtype=torch.float64, requires_grad=True)
+        drv = ShardedBatchSolve(lambda k, fl: DifferentiableFESolver(mesh, k, device="cuda:0")(fl))
+        loss, u_local = drv.step(f, lambda u, lo, hi: (u ** 2).sum(), shared_kappa=kappa)
+        # per-sample kappa: no gradient reduction, every rank keeps its shard's gradients
+        ks = torch.from_numpy(g["kappa"]).clone().requires_grad_(True)
+        loss2, _ = drv.step(f, lambda u, lo, hi: (u ** 2).sum(), sample_kappa=ks)
+        lo, hi = shard_range(len(f), rank, world)
+        torch.save(dict(loss=float(loss), grad=float(kappa.grad), loss2=float(loss2), gs=ks.grad[lo:hi].clone(), lo=lo,
+                        u=u_local.cpu()), out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_drive_the_hip_solver_through_the_sharding_layer(tmp_path):
+    """World 2 over gloo, both ranks on the one GPU of the test box: `ShardedBatchSolve` wraps the REAL
+    DifferentiableFESolver (HIP kernels), result = the loop of reference solves of fixture G9."""
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_hip_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = golden("g9_batch_2d_8")
+    B = len(g["f"])
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    # shared kappa = kappa[0] for every sample: compare with the oracle loop (G9 holds per-sample kappas)
+    mesh = (g["nodes"], g["elements"], g["bc_nodes"], g["bc_vals"])
+    k0 = float(g["kappa"][0])
+    loss_ref, grad_ref = 0.0, 0.0
+    for b in range(B):
+        uo, dk, _ = orc.solve_with_adjoint(*mesh, k0, g["f"][b], lambda u_: 2 * u_ / B)
+        loss_ref += (uo ** 2).sum() / B
+        grad_ref += dk.sum()
+    for r in (r0, r1):                                       # every rank holds the reduced values
+        assert abs(r["loss"] - loss_ref) <= 1e-10 * abs(loss_ref)
+        assert abs(r["grad"] - grad_ref) <= 1e-10 * abs(grad_ref)
+    # per-sample kappas: the reference's own per-sample gradients (G9), scaled by the 1/B of the mean loss
+    gs = torch.cat([r0["gs"], r1["gs"]]).numpy() * B
+    assert np.max(np.abs(gs - g["dkappa"])) <= 1e-10 * np.max(np.abs(g["dkappa"]))
+    assert abs(r0["loss2"] - float(g["loss"].mean())) <= 1e-10 * float(g["loss"].mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_the_hip_path():
+    """bench.py's own step (ShardedBatchSolve around the HIP solver) on 2 ranks started by `--gpus 2` itself;
+    gloo + both ranks on device 0 because the test box has one GPU."""
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--all-on-device", "0", "--mesh", "256", "--batch", "64", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-variants"], capture_output=True, text=True, timeout=800, env=clean)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["value"] > 0
+    assert res["config"]["solver"] == "lattice-mgpcg" and res["solver_iters"]["not_converged"] == 0
+    assert res["metric"].startswith("FEM solves/sec (fwd+adjoint), 2D P1 Poisson 256^2 mesh, batch=64")

@@ -276,6 +276,35 @@ def test_physics_loss_fem_match_value_and_cache():
     assert loss.fem_target() is target                          # cached: not re-solved
 
 
+def test_physics_loss_rhs_ensemble_is_one_batched_solve():
+    """SURVEY 8(f) rank 1 / fixture G12: six forcing functions -> ONE batched HIP solve; the per-member values equal
+    six separate reference `PhysicsLoss(mesh, f_k, "fem_match")(u_pred)` calls (loss.py:78-83), the targets the
+    reference's own solves."""
+    g = golden("g12_physics_loss_ensemble")
+    mesh = mesh_from(g)
+    fns = {"one": lambda x: torch.ones_like(x), "lin": lambda x: 1.0 + 2.0 * x,
+           "sin1": lambda x: (math.pi ** 2) * torch.sin(math.pi * x), "sin3": lambda x: torch.sin(3 * math.pi * x),
+           "quad": lambda x: 4.0 * x * (1.0 - x), "exp": lambda x: torch.exp(-x)}
+    loss = PhysicsLoss(mesh, forcing_fns=[fns[str(nm)] for nm in g["names"]])
+    u_pred = torch.from_numpy(g["u_pred"]).requires_grad_(True)
+    per = loss.member_losses(u_pred)
+    assert per.shape == (6,)
+    assert rel_err(per.detach().numpy(), g["fem_match"]) < 1e-12
+    assert rel_err(loss.fem_target().numpy(), g["u_fem"]) < RTOL_U
+    assert loss.solver.last_info.path.startswith("chain1d") and loss.fem_target().shape == (6, mesh.n_nodes)
+    v = loss(u_pred)
+    assert abs(float(v) - float(g["fem_match"].mean())) < 1e-13 * float(g["fem_match"].mean())
+    v.backward()
+    assert u_pred.grad is not None
+    # 2D ensemble on the lattice path: batched target == loop of single targets
+    m2 = FEMesh.rectangle(16, 16)
+    f2 = [lambda p: torch.ones(len(p), dtype=T64), lambda p: p[:, 0] + 2 * p[:, 1], lambda p: torch.sin(3 * p[:, 0])]
+    ens = PhysicsLoss(m2, forcing_fns=f2).fem_target()
+    for i, fn in enumerate(f2):
+        single = PhysicsLoss(m2, fn).fem_target()
+        assert rel_err(ens[i].numpy(), single.numpy()) < 1e-12
+
+
 def test_config2_shape_1d_10000():
     """BASELINE config 2 at its stated size -- 1D, 10 000 elements, 1024 right-hand sides, fwd + adjoint -- against
     the REFERENCE ITSELF: fixture G10 holds rows 0, 1, 1023 of the reference's own solve (dense assembly +

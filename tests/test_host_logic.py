@@ -205,6 +205,39 @@ def test_physics_loss_modes():
     assert abs(float(loss(torch.from_numpy(g["u_pred"]))) - float(g["variational"])) < 1e-13
 
 
+def test_physics_loss_ensemble_host_logic():
+    """RHS ensembles: stacking, one (stubbed) batched solve, caching, per-member values, argument errors.
+    The solve is stubbed (no GPU here); the HIP-backed value test is tests/test_gpu_parity.py (fixture G12)."""
+    mesh = FEMesh.line(10)
+
+    class Stub(torch.nn.Module):
+        calls = 0
+        kappa = torch.tensor(1.0, dtype=torch.float64)
+
+        def forward(self, f):
+            Stub.calls += 1
+            assert f.shape == (3, 11)                      # ONE call with the whole ensemble
+            return 2.0 * f
+
+    fns = [lambda x: torch.ones_like(x), lambda x: x, lambda x: x ** 2]
+    loss = PhysicsLoss(mesh, forcing_fns=fns, solver=Stub())
+    u_pred = torch.linspace(0, 1, 11, dtype=torch.float64)
+    per = loss.member_losses(u_pred)
+    x = mesh.nodes.squeeze(1)
+    expect = torch.stack([((u_pred - 2 * fn(x)) ** 2).mean() for fn in fns])
+    assert torch.allclose(per, expect, rtol=0, atol=1e-15)
+    assert abs(float(loss(u_pred)) - float(expect.mean())) < 1e-15        # mean of the member losses
+    assert Stub.calls == 1                                                 # cached across both calls
+    same = PhysicsLoss(mesh, lambda x: torch.stack([fn(x) for fn in fns]), solver=Stub())   # forcing_fn -> (B, n)
+    assert abs(float(same(u_pred)) - float(expect.mean())) < 1e-15
+    with pytest.raises(ValueError, match="exactly one"):
+        PhysicsLoss(mesh)
+    with pytest.raises(ValueError, match="exactly one"):
+        PhysicsLoss(mesh, lambda x: x, forcing_fns=fns)
+    with pytest.raises(ValueError, match="fem_match"):
+        PhysicsLoss(mesh, forcing_fns=fns, mode="variational")
+
+
 def test_neural_pde_mask_and_shapes():
     """reference tests/test_neural.py:21-37 (BC mask) without any solve."""
     mesh = FEMesh.line(10)

@@ -231,3 +231,17 @@ def test_physics_loss_ensemble_values():
     for i in range(len(g["fem_match"])):
         fm = orc.physics_loss_fem_match(*_mesh(g), 1.0, g["f"][i], g["u_pred"])
         assert abs(fm - g["fem_match"][i]) < 1e-14 * max(1.0, abs(g["fem_match"][i]))
+
+
+@pytest.mark.parametrize("name", ["g3_1d_grad_003", "g3_1d_grad_015", "g13_1d_grad_2000", "g4_2d_000", "g4_2d_007", "g4_2d_012", "g4_2d_015"])
+def test_dense_torch_baseline_matches_reference_autograd(name):
+    """oracle/torch_dense.py (the 'reference-faithful dense' CPU baseline of bench.py: vectorised assembly ->
+    torch.linalg.solve -> autograd) against the reference's own values and gradients."""
+    from oracle import torch_dense as td
+    g = golden(name)
+    assert str(g["loss_kind"]) == "sumsq"           # the baseline helper differentiates L = sum u^2
+    mesh = orc.mesh_line(int(g["n_elements"])) if "nodes" not in g else _mesh(g)
+    u, dk, df = td.differentiable_solve(*mesh, float(g["kappa"]), g["f"])
+    assert rel_err(u, g["u"]) < 1e-12
+    assert abs(dk - float(g["dkappa"])) < 1e-11 * abs(float(g["dkappa"]))
+    assert rel_err(df, g["df"]) < 1e-11
