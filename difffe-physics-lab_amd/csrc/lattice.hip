@@ -86,16 +86,18 @@ __global__ __launch_bounds__(256) void dia_apply_dot_kernel(Level L, int Bv, con
 template <typename TV>
 __global__ __launch_bounds__(256) void dia_residual_kernel(Level L, int Bv, const double* __restrict__ scale,
                                                             const TV* __restrict__ bvec, const TV* __restrict__ x,
-                                                            TV* __restrict__ r, double* __restrict__ part, int Bp) {
+                                                            TV* __restrict__ r, double* __restrict__ part, int Bp,
+                                                            int dot_bx = 0) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double ri = (double)bvec[o] - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
+    const double bi = (double)bvec[o];
+    const double ri = bi - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
     if (r) r[o] = (TV)ri;
-    s += ri * ri;
+    s += dot_bx ? bi * (double)x[o] : ri * ri;   // dot_bx: b.x, the energy x^T A x of an (almost) converged iterate
   }
   if (part) STORE_PARTIAL(part, s);
 }
@@ -172,6 +174,7 @@ struct Extra {
   const double* sub;        // M_APPLY, F_NONE: y = A x - sub_scale[b] * sub[i], sub batch-shared (n) (may be NULL)
   const double* sub_scale;  //   per-sample factor of `sub` (NULL: 1)
   const unsigned char* mask;  // M_APPLY, F_NONE: rows with mask[i] != 0 are stored as 0 (may be NULL)
+  int dot_bx;               // M_RESID, F_NONE: the partial sums hold b.x (energy of the iterate) instead of r.r
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
@@ -357,7 +360,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         } else if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
           if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) (ex.r32 + ((i64)row * W + c0w + k) * Bp)[lb] = (float)(res * rsc);
-          s += res * res;
+          s += (FUSE == F_NONE && ex.dot_bx) ? bi * xc[q] : res * res;
         } else {
           const double xo = xc[q] + omega * res * dinv;
           (po + o)[lb] = (TV)xo;
@@ -814,8 +817,15 @@ struct PcgScalars {
   const double* scale;    // S_FLOOR: per-sample operator scale (may be NULL)
   int Bv;
   int *active, *iters, *n_active;
+  // Energy-norm stop.  With a multigrid preconditioner M ~ A the dot r.z = r^T M^-1 r the CG computes anyway is the
+  // squared ENERGY norm of the error e^T A e (to the spectral equivalence of M and A, ~20 %), and b.x that of the
+  // solution: sample b stops once r.z <= tol_e2 * energy[b].
+  double* energy;         // x^T A x ~ b.x0 of the start (full-multigrid iterate), or r0.z0 from a zero start
+  double* est;            // out: last estimate sqrt(r.z / energy) per sample
+  double tol_e2;          // 0: residual criterion only
+  int have_energy;        // energy[] was set from the full-multigrid start (S_ENERGY)
 };
-enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6, S_FLOOR = 7 };
+enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6, S_FLOOR = 7, S_ENERGY = 8 };
 
 // 1024 threads: lanes over samples, 16 waves over slices of the partial list (fixed order)
 __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const double* __restrict__ part, int nblk, int Bp,
@@ -853,8 +863,15 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
       S.beta[b] = 0.0;
       S.rz[b] = 0.0;
       break;
-    case S_RZ0:  // a = r.z
+    case S_RZ0: {  // a = r.z
       S.rz[b] = a;
+      const double rs2 = S.rs ? S.rs[b] * S.rs[b] : 1.0;   // z carries rs, so does the copy of r it is dotted with
+      if (!S.have_energy) S.energy[b] = a / rs2;           // zero start: r0.z0 = b^T M^-1 b ~ u^T A u
+      S.est[b] = S.energy[b] > 0.0 ? sqrt(a / rs2 / S.energy[b]) : 0.0;
+      break;
+    }
+    case S_ENERGY:  // a = b.x0
+      S.energy[b] = a;
       break;
     case S_ALPHA:  // a = p.Ap
       // with scaled fp32 copies z, p and Ap carry the factor rs and both dots rs^2: alpha is unchanged, and the
@@ -865,19 +882,21 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
     case S_CONV:  // a = r.r after the update
       if (S.active[b]) {
         S.iters[b] += 1;
-        if (a <= S.tol2[b])
-          S.active[b] = 0;
-        else
-          atomicAdd(S.n_active, 1);
+        if (a <= S.tol2[b]) S.active[b] = 0;
       }
       break;
     case S_BETA:  // a = r.z (new)
       if (S.active[b]) {
         S.beta[b] = a / S.rz[b];
         S.rz[b] = a;
+        const double rs2 = S.rs ? S.rs[b] * S.rs[b] : 1.0;
+        const double e2 = a / rs2;                                   // ~ e^T A e of the current iterate
+        S.est[b] = S.energy[b] > 0.0 ? sqrt(fmax(e2, 0.0) / S.energy[b]) : 0.0;
+        if (S.tol_e2 > 0.0 && e2 <= S.tol_e2 * S.energy[b]) S.active[b] = 0;
       } else {
         S.beta[b] = 0.0;
       }
+      if (S.active[b]) atomicAdd(S.n_active, 1);                      // read by the host after this phase
       break;
     case S_SUM:  // plain per-sample total
       relres[b] = a;
@@ -959,14 +978,18 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
 }
 
 template <typename TV>
-int op_residual(const Hier& H, int l, const TV* rhs, const TV* x, TV* res, double* part, hipStream_t st) {
+int op_residual(const Hier& H, int l, const TV* rhs, const TV* x, TV* res, double* part, hipStream_t st,
+                int dot_bx = 0) {
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp);
   if (g.use) {
-    launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st);
+    Extra ex{};
+    ex.dot_bx = dot_bx;
+    launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st, ex);
     return g.ncb * g.nrc;
   }
-  LAUNCH((res ? 3 : 2) * sizeof(TV) + MATB(L), dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp);
+  LAUNCH((res ? 3 : 2) * sizeof(TV) + MATB(L), dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp,
+         dot_bx);
   return lgrid(L.n, H.Bp).x;
 }
 
@@ -1231,9 +1254,9 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
-                                        const double* b, double* x, int Bp, double tol, int max_iter, int nu,
-                                        int n_coarse, const double* omegas_host, int precond_fp32, double* work,
-                                        double* relres, int* iters, int* status_host, void* stream) {
+                                        const double* b, double* x, int Bp, double tol, double tol_energy, int max_iter,
+                                        int nu, int n_coarse, const double* omegas_host, int precond_fp32, double* work,
+                                        double* relres, double* err_est, int* iters, int* status_host, void* stream) {
   if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0) return DIFFHE_E_BADARG;
   Hier H;
   int rc = fill_hier(H, levels, n_levels, Bv, Bp, scale, omegas_host, nu, n_coarse);
@@ -1265,6 +1288,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.rs = f32 ? sc + 11 * Bp : nullptr;
   S.scale = scale;
   S.Bv = Bv;
+  S.energy = sc + 12 * Bp;
+  S.est = err_est ? err_est : sc + 13 * Bp;
+  S.tol_e2 = tol_energy > 0.0 ? tol_energy * tol_energy : 0.0;
+  S.have_energy = 0;
   if (use_floor && use_fmg) {
     rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));
     if (rc) return rc;
@@ -1345,11 +1372,15 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       Extra ex{};
       ex.r32 = r32;
       ex.rscale = S.rs;
-      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, nullptr, Bp, gr, st, ex);
+      ex.dot_bx = 1;   // the partial sums of this pass: b.x0, the energy of the start (S_ENERGY)
+      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, partA, Bp, gr, st, ex);
+      nba = gr.ncb * gr.nrc;
     } else {
-      op_residual<double>(H, 0, b, (const double*)x, r, nullptr, st);
+      nba = op_residual<double>(H, 0, b, (const double*)x, r, partA, st, 1);
       if (f32) LAUNCH(12.0, pcg_cvt_kernel, n, (const double*)r, (const double*)S.rs, r32, n, Bp);
     }
+    SCALAR(S_ENERGY, partA, nba);
+    S.have_energy = 1;
   }
   precondition(1);
   rc = diffhe::check_launch();
@@ -1363,10 +1394,11 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
            r, r32, (const double*)S.rs, partA, n, Bp);
     SCALAR(S_CONV, partA, nblk);
     ++it;
+    // z = V(r) and r.z: the new search direction's ingredients AND the energy-norm error estimate of the iterate;
+    // the samples still active are counted in the scalar phase behind it (S_BETA)
+    precondition(0);
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
     if (rc) return rc;
-    // overlap the convergence read-back with the next V-cycle: enqueue it first, then wait
-    precondition(0);
     rc = diffhe::check(hipStreamSynchronize(st));
     if (rc) return rc;
     n_active = status_host[2];

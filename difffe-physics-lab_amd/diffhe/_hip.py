@@ -55,8 +55,8 @@ SIGNATURES = {
     "diffhe_ell_amg_pcg_solve": (_I, [_AV, _I, _I, _P, _P, _I, _D, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P]),
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pcg_workspace_doubles": (_L, [_LV, _I, _I]),
-    "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P, _P,
-                                      _P, _P]),
+    "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P,
+                                      _P, _P, _P, _P]),
     "diffhe_lattice_pcg_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_lattice_blocks": (_I, [_I, _I]),
     "diffhe_lattice_apply": (_I, [_LV, _I, _P, _P, _P, _P, _I, _P]),

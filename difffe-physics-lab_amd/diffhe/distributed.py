@@ -38,8 +38,15 @@ def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None) -> None:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    if flat.numel() * flat.element_size() >= _TWO_PHASE_BYTES and dist.get_backend(group) == "nccl":
+    nccl = dist.get_backend(group) == "nccl"
+    # one staging device for the fused message: RCCL needs device memory; gloo reduces on the host (the loss may
+    # live on the GPU while a shared kappa -- and hence its gradient -- is a CPU tensor, as in the reference's API)
+    cuda = [t.device for t in tensors if t.is_cuda]
+    if nccl and not cuda:
+        raise RuntimeError("allreduce_sum_fused over RCCL needs at least one tensor on the GPU")
+    target = cuda[0] if nccl else torch.device("cpu")
+    flat = torch.cat([t.detach().reshape(-1).to(target) for t in tensors])
+    if flat.numel() * flat.element_size() >= _TWO_PHASE_BYTES and nccl:
         n = flat.numel()
         per = (n + world - 1) // world
         padded = torch.zeros(per * world, dtype=flat.dtype, device=flat.device)
@@ -51,9 +58,10 @@ def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None) -> None:
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
-    for t in tensors:
-        t.copy_(flat[off:off + t.numel()].reshape(t.shape))
-        off += t.numel()
+    with torch.no_grad():
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].reshape(t.shape))      # back to each tensor's own device
+            off += t.numel()
 
 
 class ShardedBatchSolve:

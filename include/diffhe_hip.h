@@ -250,14 +250,21 @@ typedef struct diffhe_mg_level {
  *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the
  *            iterate no longer improves (the same backward error a direct fp64 solve, solver.py:174, reaches)
  *   tol      relative residual |r|_2 / |b|_2 per sample
+ *   tol_energy  > 0: sample b ALSO stops once the estimated relative energy-norm error of its iterate,
+ *            sqrt(r.z / u^T A u), is <= tol_energy.  r.z = r^T M^-1 r is the dot the CG needs for beta anyway;
+ *            with the multigrid preconditioner M ~ A it equals e^T A e to the spectral equivalence of M and A;
+ *            u^T A u ~ b.x0 of the full-multigrid start (r0.z0 from a zero start).  Nodal and per-element-gradient
+ *            errors are what the parity tolerance is stated in, and the energy norm bounds both far more tightly
+ *            than the residual does (1024^2, f = 1: relative residual 6e-9 <-> nodal error 6e-12).  0: off.
+ *   err_est  (Bp) out or NULL: the last estimate per sample
  *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */
 long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp);
 int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
-                             const double* b, double* x, int Bp, double tol, int max_iter, int nu, int n_coarse,
-                             const double* omegas_host, int precond_fp32, double* work, double* relres,
-                             int* iters, int* status_host, void* stream);
+                             const double* b, double* x, int Bp, double tol, double tol_energy, int max_iter, int nu,
+                             int n_coarse, const double* omegas_host, int precond_fp32, double* work, double* relres,
+                             double* err_est, int* iters, int* status_host, void* stream);
 /* Opt-in timing of the fused CG-step kernel (the dominant one) inside diffhe_lattice_pcg_solve's own loop, for
  * bench.py's roofline entry: enable = 1 creates two HIP events (per calling thread, the only hidden state in the
  * library, and only in this mode) and resets the counters, 0 stops, < 0 only reads.  The events bracket each launch

@@ -353,7 +353,7 @@ def physics_loss_variational(nodes, bc_nodes, f, u_pred):
 # Extended-precision reference for ill-conditioned 1D chains
 # ---------------------------------------------------------------------------
 
-def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None):
+def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None, reference_rounding=False):
     """The SAME discrete system as `assemble_dense` + `apply_bc_and_solve` for a chain mesh
     (elements[e] = (e, e+1); reference solver.py:73-98, :153-183), but assembled and
     LU-factorised (tridiagonal, no pivoting: the matrix is SPD) in numpy.longdouble.
@@ -363,16 +363,26 @@ def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None):
     solution (measured: dense LAPACK and SuperLU agree with each other to 5e-15 and both
     differ from this routine by 4.04e-10).  Parity at that size is judged against this
     routine, and the fp64 oracle's own distance to it is reported next to ours.
+    reference_rounding=True: the matrix and load are the ones the reference ASSEMBLES IN FP64 -- weights
+    k_e = fl(kappa/h_e), diagonal fl(k_{i-1} + k_i) (solver.py:88-92), F_i = fl(h/2 f_i) summed in element order
+    (solver.py:95-96) -- and only the SOLVE runs in extended precision: the exact solution of the reference's own
+    rounded system, the yardstick of the HIP path's reference-order chain mode where the fp64 LU's forward error
+    (up to 3e-10 in per-element gradients at 10^4 elements, measured) is in the way.
     Returns u (and, with gbar_fn, dkappa per element and df) as float64.
     """
     LD = np.longdouble
-    x = np.asarray(nodes, dtype=np.float64)[:, 0].astype(LD)
+    x64 = np.asarray(nodes, dtype=np.float64)[:, 0]
+    x = x64.astype(LD)
     n = len(x)
-    h = x[1:] - x[:-1]                                   # solver.py:84-86
+    h = x[1:] - x[:-1]                                   # solver.py:84-86  (exact: a difference of two doubles
+    #                                                      is representable in 64-bit-mantissa long double)
     k = _kappa_per_element(kappa, n - 1).astype(LD) / h  # solver.py:88
     w = np.zeros(n, dtype=LD)
     w[:-1] += h / 2
     w[1:] += h / 2                                       # solver.py:95-96
+    if reference_rounding:
+        h64 = x64[1:] - x64[:-1]
+        k = (_kappa_per_element(kappa, n - 1) / h64).astype(LD)
     is_bc = np.zeros(n, dtype=bool)
     g = np.zeros(n, dtype=LD)
     is_bc[np.asarray(bc_nodes, dtype=np.int64)] = True
@@ -380,6 +390,11 @@ def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None):
     diag = np.zeros(n, dtype=LD)
     diag[:-1] += k
     diag[1:] += k                                        # solver.py:89,92
+    if reference_rounding:
+        d64 = np.zeros(n)
+        d64[1:] += k.astype(np.float64)                  # K[j,j] += k_e comes first for node j = e+1 ...
+        d64[:-1] = d64[:-1] + k.astype(np.float64)       # ... then K[i,i] += k_{e+1}: fl(k_{i-1} + k_i)
+        diag = d64.astype(LD)
     off = -k                                             # solver.py:90-91
 
     def tri_solve(rhs):
@@ -411,6 +426,12 @@ def chain_solve_longdouble(nodes, bc_nodes, bc_vals, kappa, f, gbar_fn=None):
         return sol
 
     F = np.asarray(f, dtype=np.float64).astype(LD) * w
+    if reference_rounding:
+        f64 = np.asarray(f, dtype=np.float64)
+        F64 = np.zeros(n)
+        F64[1:] = (h64 / 2.0) * f64[1:]
+        F64[:-1] = F64[:-1] + (h64 / 2.0) * f64[:-1]
+        F = F64.astype(LD)
     rhs = F.copy()
     # lifting: F_free -= K[free,bc] g  (solver.py:166-169)
     for i in range(n):

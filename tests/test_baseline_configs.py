@@ -1,0 +1,175 @@
+"""BASELINE.json configs 3, 4 and 5 at their STATED sizes on one MI355X (per-GPU shard where the config names 8
+GPUs), through the Python boundary: parity against the oracle on several samples (first, middle, last), the exact
+DST-I solution of the assembled 5-point system, the identity dL/dkappa = -2L/kappa, and recorded throughput.
+Config 1 is `test_forward_golden[g1_config1]`, config 2 `test_config2_shape_1d_10000` (tests/test_gpu_parity.py).
+Inputs follow SURVEY 8(d): seeds 2024 / 2025 (C3), 4096 (C4), 5 (C5)."""
+import concurrent.futures as cf
+import multiprocessing as mp
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from diffhe import FEMesh, DifferentiableFESolver
+from oracle import p1_oracle as orc
+from _util import rel_err, RTOL_U, RTOL_GRAD
+
+pytestmark = pytest.mark.gpu
+T64 = torch.float64
+DEV = "cuda:0"
+
+
+def _arrays(mesh):
+    bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
+    bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
+    return mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv
+
+
+def _oracle_job(job):
+    nodes, el, bn, bv, kappa, f, scale = job
+    u, dk, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kappa, f, lambda u_: scale * u_, sparse=True)
+    return u, dk
+
+
+def _oracle_many(mesh, kappas, fs, scale):
+    """fwd + adjoint of the oracle (SuperLU) for several samples, one per worker process (fresh interpreters:
+    this process holds a GPU context)."""
+    nodes, el, bn, bv = _arrays(mesh)
+    jobs = [(nodes, el, bn, bv, k, f, scale) for k, f in zip(kappas, fs)]
+    with cf.ProcessPoolExecutor(len(jobs), mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_oracle_job, jobs))
+
+
+def _dst_unit_square(N, kappa, F_interior):
+    from scipy.fft import dstn, idstn
+    k = np.arange(1, N)
+    lam = 4.0 - 2.0 * np.cos(np.pi * k / N)[:, None] - 2.0 * np.cos(np.pi * k / N)[None, :]
+    return idstn(dstn(F_interior, type=1) / (kappa * lam), type=1)
+
+
+def _step(mesh, kappa, f):
+    solver = DifferentiableFESolver(mesh, kappa, device=DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    u = solver(f)
+    L = (u ** 2).sum(dim=1)
+    L.mean().backward()
+    torch.cuda.synchronize()
+    return solver, u, L.detach(), time.perf_counter() - t0
+
+
+@pytest.mark.timeout(900)
+def test_config3_512_batch256_scalar_kappa():
+    """Config 3: rectangle(512, 512), 256 samples, kappa_b ~ U(0.5, 2) seed 2024, f = 1, fwd + adjoint."""
+    N, B = 512, 256
+    mesh = FEMesh.rectangle(N, N)
+    gen = torch.Generator().manual_seed(2024)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(DEV).requires_grad_(True)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=DEV)
+    _step(mesh, kappa, f)                                       # warm-up (plan build)
+    kappa.grad = None
+    solver, u, L, dt = _step(mesh, kappa, f)
+    print(f"config 3 (512^2 x 256, scalar kappa): {B / dt:.0f} differentiable solves/s, iterations "
+          f"{solver.last_info.iterations}+{solver.last_info.adj_iterations}")
+    assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.not_converged == 0
+    ref = -2.0 * L / kappa.detach() / B                        # dL/dkappa = -2 L_b / kappa_b (mean over B)
+    assert float(((kappa.grad - ref).abs() / ref.abs()).max()) < RTOL_GRAD
+    # exact solution of the assembled 5-point system (F = h^2 on the interior for f = 1), every sample
+    F = orc.load_vector(*_arrays(mesh)[:2], np.ones(mesh.n_nodes)).reshape(N + 1, N + 1)[1:-1, 1:-1]
+    u1 = np.zeros((N + 1, N + 1))
+    u1[1:-1, 1:-1] = _dst_unit_square(N, 1.0, F)
+    ue = torch.from_numpy(u1.ravel()).to(DEV)[None, :] / kappa.detach()[:, None]
+    assert float((u.detach() - ue).abs().max() / ue.abs().max()) < RTOL_U
+    # oracle (reference-order assembly + LU) on the first, a middle and the last sample
+    idx = [0, 100, B - 1]
+    res = _oracle_many(mesh, [float(kappa[b]) for b in idx], [np.ones(mesh.n_nodes)] * 3, 2.0 / B)
+    for b, (uo, dk) in zip(idx, res):
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert abs(float(kappa.grad[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+
+
+@pytest.mark.timeout(900)
+def test_config3_512_batch256_per_element_kappa_field():
+    """Config 3, per-element variant: an independent log-normal field exp(0.3 randn) per sample (seed 2025)."""
+    N, B = 512, 256
+    mesh = FEMesh.rectangle(N, N)
+    gdev = torch.Generator(device=DEV).manual_seed(2025)
+    kappa = torch.exp(0.3 * torch.randn(B, mesh.n_elements, generator=gdev, dtype=T64, device=DEV)).requires_grad_(True)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=DEV)
+    _step(mesh, kappa, f)
+    kappa.grad = None
+    solver, u, L, dt = _step(mesh, kappa, f)
+    print(f"config 3 (512^2 x 256, per-element kappa field): {B / dt:.0f} differentiable solves/s, iterations "
+          f"{solver.last_info.iterations}+{solver.last_info.adj_iterations}")
+    assert solver.last_info.not_converged == 0
+    idx = [0, B - 1]
+    res = _oracle_many(mesh, [kappa[b].detach().cpu().numpy() for b in idx], [np.ones(mesh.n_nodes)] * 2, 2.0 / B)
+    for b, (uo, dk) in zip(idx, res):
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(kappa.grad[b].cpu().numpy(), dk) < RTOL_GRAD
+    # sum_e kappa_e dL/dkappa_e = -2 L (Euler: u is homogeneous of degree -1 in the field)
+    euler = (kappa.grad * kappa.detach()).sum(dim=1) * B
+    assert float(((euler + 2.0 * L).abs() / (2.0 * L)).max()) < RTOL_GRAD
+
+
+@pytest.mark.timeout(1200)
+def test_config4_shard_1024_batch256():
+    """Config 4's per-GPU shard: rectangle(1024, 1024), 256 of the 2048 samples (seed 4096 = rank 0's shard, the
+    bench workload), fwd + adjoint; parity on the first, a middle and the LAST sample."""
+    N, B = 1024, 256
+    mesh = FEMesh.rectangle(N, N)
+    gen = torch.Generator().manual_seed(4096)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(DEV).requires_grad_(True)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=DEV)
+    _step(mesh, kappa, f)
+    kappa.grad = None
+    solver, u, L, dt = _step(mesh, kappa, f)
+    print(f"config 4 shard (1024^2 x 256): {B / dt:.0f} differentiable solves/s, iterations "
+          f"{solver.last_info.iterations}+{solver.last_info.adj_iterations}")
+    assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.not_converged == 0
+    ref = -2.0 * L / kappa.detach() / B
+    assert float(((kappa.grad - ref).abs() / ref.abs()).max()) < RTOL_GRAD
+    idx = [0, 127, B - 1]
+    res = _oracle_many(mesh, [float(kappa[b]) for b in idx], [np.ones(mesh.n_nodes)] * 3, 2.0 / B)
+    for b, (uo, dk) in zip(idx, res):
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert abs(float(kappa.grad[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+
+
+@pytest.mark.timeout(900)
+def test_config5_kappa_recovery_512_batch64_100_adam_steps():
+    """Config 5's per-GPU shard (tools/kappa_recovery.py): 512^2, 64 samples (seed 5), kappa_0 = 1, Adam lr 0.1 on
+    kappa.abs() exactly like examples/poisson_1d_demo.py:102-110, 100 steps through the adjoint solve."""
+    N, B, STEPS = 512, 64, 100
+    mesh = FEMesh.rectangle(N, N)
+    gen = torch.Generator().manual_seed(5)
+    k_true = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(DEV)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=DEV)
+    with torch.no_grad():
+        u_data = DifferentiableFESolver(mesh, k_true, device=DEV)(f)
+    k = torch.ones(B, dtype=T64, device=DEV, requires_grad=True)
+    opt = torch.optim.Adam([k], lr=0.1)
+    scale = 1.0 / float((u_data ** 2).mean())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first = None
+    for step in range(STEPS):
+        opt.zero_grad()
+        u = DifferentiableFESolver(mesh, k.abs(), device=DEV)(f)
+        loss = ((u - u_data) ** 2).mean(dim=1).sum() * scale
+        loss.backward()
+        if step == 0:
+            first = float(loss.detach())
+            # the data term's gradient through the adjoint: d/dk of mean((u0/k - u_data)^2) at k = 1, closed form
+            with torch.no_grad():
+                u0 = u.detach()
+                expect = (2.0 * (u0 - u_data) * (-u0)).mean(dim=1) * scale
+            assert float(((k.grad - expect).abs() / expect.abs()).max()) < 1e-9
+        opt.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = float((k.detach().abs() - k_true).abs().max())
+    print(f"config 5 shard (512^2 x 64, {STEPS} Adam steps): {STEPS / dt:.1f} steps/s = {STEPS * B / dt:.0f} "
+          f"differentiable solves/s; max |kappa - kappa_true| = {err:.2e}; loss {first:.3e} -> {float(loss.detach()):.3e}")
+    assert err < 2e-2 and float(loss.detach()) < 1e-3 * first

@@ -836,10 +836,12 @@ def test_unstructured_mesh_amg_vs_oracle(N, B):
 
 
 def _chain_oracle(mode, nodes, el, bn, bv, kappa, f, gbar_fn):
-    """reference mode: the fp64 oracle (the reference's rounded system, LU); exact mode: extended precision."""
-    if mode == "reference":
-        return orc.solve_with_adjoint(nodes, el, bn, bv, kappa, f, gbar_fn, sparse=True)
-    return orc.chain_solve_longdouble(nodes, bn, bv, kappa, f, gbar_fn)
+    """Extended-precision solve of the system each chain mode stands for: "reference" = the matrix and load the
+    reference assembles in fp64 (rounded weights and diagonal), "exact" = the unrounded weighted Laplacian.
+    (The fp64 LU of the oracle / the reference is itself up to 3e-10 off in per-element gradients at these sizes --
+    measured against this routine -- so it cannot be the yardstick here; at 10^4 uniform elements the reference's
+    own solve IS the yardstick: test_config2_shape_1d_10000.)"""
+    return orc.chain_solve_longdouble(nodes, bn, bv, kappa, f, gbar_fn, reference_rounding=(mode == "reference"))
 
 
 @pytest.mark.gpu
@@ -1032,7 +1034,7 @@ def test_per_element_gradients_on_rough_data_at_strip_size():
     solver = DifferentiableFESolver(mesh, kt)
     u = solver(ft)
     (u ** 2).sum().backward()
-    assert solver.tol == 1e-14 and solver.mg["floor"] == 0 and solver.last_info.not_converged == 0
+    assert solver.tol == 1e-14 and solver.last_info.not_converged == 0
     for b in (0, B - 1):
         uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kap[b], f[b], lambda u: 2 * u)
         assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
@@ -1082,3 +1084,21 @@ def test_assembled_operators_are_bit_identical_to_the_reference_order():
             ref = np.asarray(K[i[ok], j[ok]]).ravel(); got = v[k, ok]; nz = ref != 0
             tot += nz.sum(); diff += (got[nz] != ref[nz]).sum()
         assert tot > 0 and diff == 0, (jitter, diff)
+
+
+@pytest.mark.gpu
+def test_per_call_options_do_not_stick_to_the_solver():
+    """A per-element call runs without the residual floor and to 1e-14; the user's mg / amg settings and the
+    scalar-kappa default tolerance are what the NEXT call sees (nothing is written back into the solver)."""
+    mesh = FEMesh.rectangle(320, 320)
+    f = torch.ones(2, mesh.n_nodes, dtype=T64)
+    solver = DifferentiableFESolver(mesh, torch.tensor([1.0, 2.0], dtype=T64))
+    mg0, amg0 = dict(solver.mg), dict(solver.amg)
+    solver(f)
+    tol_scalar = solver.tol
+    solver._kappa = torch.rand(2, mesh.n_elements, dtype=T64) + 0.5
+    solver(f)
+    assert solver.tol == 1e-14 and solver.mg == mg0 and solver.amg == amg0
+    solver._kappa = torch.tensor([1.0, 2.0], dtype=T64)
+    solver(f)
+    assert solver.tol == tol_scalar == 1e-12

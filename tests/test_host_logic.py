@@ -334,3 +334,12 @@ def test_aggregation_hierarchy_galerkin_lists():
         members = lv["agg_members"]
         assert np.array_equal(np.sort(members), np.nonzero(act)[0])
         A, v = Ac, vc
+
+
+def test_lattice_gather_lists_are_the_sorted_definition():
+    """The analytic gather lists of a lattice (plan.build_dia_pattern) equal the stable sort over all local entries."""
+    from diffhe.plan import _build_dia_pattern_sorted
+    for nx, ny in ((2, 2), (3, 2), (2, 5), (7, 5), (16, 9)):
+        a, b = build_dia_pattern(nx, ny), _build_dia_pattern_sorted(nx, ny)
+        for key in ("cols", "ent_ptr", "contrib"):
+            assert np.array_equal(a[key], b[key]) and a[key].dtype == b[key].dtype, (nx, ny, key)

@@ -245,3 +245,20 @@ def test_dense_torch_baseline_matches_reference_autograd(name):
     assert rel_err(u, g["u"]) < 1e-12
     assert abs(dk - float(g["dkappa"])) < 1e-11 * abs(float(g["dkappa"]))
     assert rel_err(df, g["df"]) < 1e-11
+
+
+def test_longdouble_chain_oracle_with_reference_rounding():
+    """chain_solve_longdouble(reference_rounding=True) = the exact solution of the system the reference assembles in
+    fp64: at 10^4 elements it is 7e-12 from the reference's own LU result (fixture G10) -- the LU's forward error --
+    where the unrounded system is 4e-10 away."""
+    g = golden("g10_config2_1d_10000")
+    nodes, el, bn, bv = orc.mesh_line(int(g["n_elements"]))
+    ur = orc.chain_solve_longdouble(nodes, bn, bv, 1.0, g["f"][0], reference_rounding=True)
+    assert rel_err(ur, g["u"][0]) < 2e-11
+    for name in ("g3_1d_grad_015", "g13_1d_grad_2000"):
+        h = golden(name)
+        mesh = orc.mesh_line(int(h["n_elements"])) if "nodes" not in h else _mesh(h)
+        u, dk, df = orc.chain_solve_longdouble(mesh[0], mesh[2], mesh[3], float(h["kappa"]), h["f"], lambda u_: 2 * u_,
+                                               reference_rounding=True)
+        assert rel_err(u, h["u"]) < 1e-11 and rel_err(df, h["df"]) < 1e-11
+        assert abs(dk.sum() - float(h["dkappa"])) < 1e-11 * abs(float(h["dkappa"]))
