@@ -15,7 +15,8 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_jacobi_kernel")
+KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
+        "pcg_cvt_kernel", "pcg_axpy_kernel", "to_node_major_kernel", "to_sample_major_kernel")
 
 
 def short(name):
@@ -39,18 +40,30 @@ def collect(d, counter):
 def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
     log = os.path.join(os.path.dirname(sys.argv[1].rstrip("/")), os.path.basename(sys.argv[1].rstrip("/")) + ".log")
-    pass_bytes = 1024 * 1024 * 8 * 256 if not os.path.exists(log) else None
-    if pass_bytes is None:
+    pass_bytes = None
+    if os.path.exists(log):
         for line in open(log):
             if line.startswith("pass_bytes"):
                 pass_bytes = int(line.split()[1])
+    if pass_bytes is None:
+        pass_bytes = 1025 * 1025 * 8 * 256       # one fp64 vector of the bench workload
     out = {"pass_bytes": pass_bytes, "kernels": {}}
+    try:        # algorithmic passes per launch of the kernels of the bench step (tools/roofline_table.py)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from roofline_table import RULES
+    except Exception:
+        RULES = []
     for k in sorted(set(fetch) & set(write)):
         rd, wr = 2.0 * fetch[k] * 1024.0, write[k] * 1024.0
         out["kernels"][k] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "read_bytes_corrected": rd,
                              "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                              "passes": (rd + wr) / pass_bytes, "read_passes": rd / pass_bytes,
                              "write_passes": wr / pass_bytes}
+        for key, label, passes in RULES:
+            if key in k:
+                out["kernels"][k].update(label=label, algorithmic_passes=passes,
+                                         traffic_over_algorithmic=(rd + wr) / pass_bytes / passes)
+                break
     text = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(text + "\n")
