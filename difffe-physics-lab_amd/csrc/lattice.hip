@@ -26,6 +26,7 @@ struct Level {
   const double* v;          // (nd, n, Bv)
   const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels (Bv == Bp)
   const unsigned char* bc;  // (n)
+  const void* inv;          // optional dense inverse (n, n) of a batch-shared level matrix, in the V-cycle's storage type
 };
 
 // 1/d for the smoother: hardware v_rcp_f64 (~2^-23 relative) + one Newton step (~1e-14) -- 4 instructions
@@ -936,8 +937,11 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
         // (a V-cycle that lost definiteness -- obtuse meshes, fp32 overflow -- can return anything), a positive
         // energy bound, and a residual already within 1e4 x the target (|r|/|b| is 6e-9 .. 2e-10 at the iterations
         // where the bench workload stops); otherwise the residual criterion decides alone.
+        // ... and only within the first 10 iterations: r.z equals e^T A e up to lambda_min(M^-1 A), and a CG that needs
+        // more than that to get here is telling that this constant is small (skewed lattices with pinned interior
+        // nodes: 12 and 35 iterations, error 8e-11 at an estimate of 1e-11).
         if (S.tol_e2 > 0.0 && a > 0.0 && S.energy[b] > 0.0 && e2 <= S.tol_e2 * S.energy[b] &&
-            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b])
+            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b] && S.iters[b] <= 10)
           S.active[b] = 0;
       } else {
         S.beta[b] = 0.0;
@@ -1051,6 +1055,67 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
   return lgrid(L.n, H.Bp).x;
 }
 
+// Coarsest-level solve with a precomputed dense inverse of the batch-shared level matrix (K_1 of a factored
+// operator, plan-constant): x[i, b] = (1 / s_b) sum_j inv[i, j] rhs[j, b].  A wave owns RPW rows x 64 samples: rhs is
+// read once per wave (lanes over samples, 256-512 B per load, L2-resident at these sizes), the inverse arrives as
+// wave-uniform scalar loads.  33^2 nodes x 256 samples: 3e8 multiply-adds in ONE launch instead of the ~45 launches
+// (5 levels of sweeps, transfers and the Chebyshev solve of the 3 x 3 grid) it replaces -- those were
+// launch-latency-bound at ~5 us each.  Exact (to fp32/fp64 rounding) and symmetric, so the cycle stays an SPD
+// preconditioner.
+template <typename TV, int RPB>
+__global__ __launch_bounds__(256) void mg_dense_solve_kernel(int n, const TV* __restrict__ inv,
+                                                              const double* __restrict__ scale,
+                                                              const TV* __restrict__ rhs, TV* __restrict__ x,
+                                                              double* __restrict__ part, int Bp) {
+  // block = RPB rows x 64 samples; its 4 waves split the sum over j (a quarter each, 4 loads in flight per wave:
+  // one wave per SIMD with one dependent L2 load per step ran 260 us), partial rows meet in LDS
+  __shared__ double red[4 * RPB * kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y * kWave + lane;
+  const int i0 = blockIdx.x * RPB;
+  const int nq = (n + 3) / 4;
+  const int j0 = wave * nq, j1 = (j0 + nq < n) ? j0 + nq : n;
+  double acc[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) acc[r] = 0.0;
+  const TV* __restrict__ row[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) row[r] = inv + (i64)(i0 + r < n ? i0 + r : n - 1) * n;
+  const TV* __restrict__ rb = rhs + b;
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    const double v0 = (double)rb[(i64)j * Bp], v1 = (double)rb[(i64)(j + 1) * Bp];
+    const double v2 = (double)rb[(i64)(j + 2) * Bp], v3 = (double)rb[(i64)(j + 3) * Bp];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r)
+      acc[r] += ((double)row[r][j] * v0 + (double)row[r][j + 1] * v1) + ((double)row[r][j + 2] * v2 + (double)row[r][j + 3] * v3);
+  }
+  for (; j < j1; ++j) {
+    const double v = (double)rb[(i64)j * Bp];
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) acc[r] += (double)row[r][j] * v;
+  }
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) red[(wave * RPB + r) * kWave + lane] = acc[r];
+  __syncthreads();
+  double s = 0.0;
+  if (wave == 0) {
+    const double si = scale ? 1.0 / scale[b] : 1.0;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) {
+      if (i0 + r < n) {
+        const double t = (red[r * kWave + lane] + red[(RPB + r) * kWave + lane]) +
+                         (red[(2 * RPB + r) * kWave + lane] + red[(3 * RPB + r) * kWave + lane]);
+        const double xo = si * t;
+        x[(i64)(i0 + r) * Bp + b] = (TV)xo;
+        s += (double)rb[(i64)(i0 + r) * Bp] * xo;
+      }
+    }
+    if (part) part[(i64)blockIdx.x * Bp + b] = s;  // rhs . x partials (only when this level is the whole cycle)
+  }
+}
+
 // Coarsest-level solve: Chebyshev semi-iteration for D^-1 A with the spectrum bounds of the P1 Laplacian
 // on an nx x ny lattice, lambda in [ (1 - cos(pi/nx))/2 + (1 - cos(pi/ny))/2 , 2 ]; the lower bound is halved
 // for safety (below it the polynomial stays < 1, it only damps less).  The degree follows from the size, so a
@@ -1059,6 +1124,15 @@ int op_apply_dot(const Hier& H, const double* x, double* y, double* part, hipStr
 template <typename TV>
 TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks, hipStream_t st) {
   const Level& L = H.lev[l];
+  if (L.inv && H.Bv == 1 && H.Bp >= kWave) {  // dense inverse of the shared level matrix: one launch
+    constexpr int RPB = 4;
+    const dim3 grid((L.n + RPB - 1) / RPB, H.Bp / kWave);
+    diffhe::account(2.0 * sizeof(TV) * (double)L.n * H.Bp);
+    hipLaunchKernelGGL((mg_dense_solve_kernel<TV, RPB>), grid, dim3(256), 0, st, L.n, (const TV*)L.inv, H.scale, rhs,
+                       (TV*)H.xa[l], part, H.Bp);
+    if (nblocks) *nblocks = grid.x;
+    return (TV*)H.xa[l];
+  }
   const double pi = 3.14159265358979323846;
   const double lmin = 0.5 * (0.5 * (1.0 - cos(pi / L.nx)) + 0.5 * (1.0 - cos(pi / L.ny)));
   const double lmax = H.coarse_lmax;
@@ -1259,7 +1333,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;

@@ -359,6 +359,33 @@ class SolvePlan:
         if not self.is_lattice:
             self.ensure_ell()
 
+    def dense_coarse(self, vals, fp32: bool, max_nodes: int = 1200):
+        """(level index, dense inverse) for the factored lattice operator, or None.  `vals` are the UNIT-kappa
+        symmetric diagonals of every level (plan-constant, so the inverse is built once and cached): the first
+        level with at most `max_nodes` nodes (33 x 33 for power-of-two meshes) is inverted on the host -- identity
+        rows stay identity -- and uploaded in the V-cycle's storage type.  None when the hierarchy has no such
+        level below level 0 (sizes that stop halving early keep the Chebyshev coarse solve)."""
+        idx = next((i for i, lev in enumerate(self.levels) if i > 0 and lev.n <= max_nodes), None)
+        if idx is None:
+            return None
+        key = (idx, bool(fp32))
+        cache = self.__dict__.setdefault("_dense_cache", {})
+        if key not in cache:
+            lev = self.levels[idx]
+            d = vals[idx].detach().to("cpu", torch.float64).numpy().reshape(lev.nd, lev.n)
+            n, W = lev.n, lev.nx + 1
+            K = np.zeros((n, n))
+            i = np.arange(n)
+            K[i, i] = d[0]
+            for k, off in ((1, 1), (2, W)) + (((3, lev.nx),) if lev.nd == 4 else ()):
+                j = i[: n - off]
+                K[j, j + off] = d[k][: n - off]
+                K[j + off, j] = d[k][: n - off]
+            inv = np.linalg.inv(K)
+            inv = 0.5 * (inv + inv.T)                        # symmetric to the last bit: the cycle stays symmetric
+            cache[key] = torch.from_numpy(inv.astype(np.float32) if fp32 else inv).to(self.device).contiguous()
+        return idx, cache[key]
+
     def ensure_ell(self):
         """ELL pattern, gather lists, element integrals and the ELL load matrix of the general path."""
         if self._ell_ready:

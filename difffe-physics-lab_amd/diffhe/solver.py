@@ -244,18 +244,22 @@ class _Engine:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def lattice_levels(self, vals, vals32=None):
-        arr = (_hip.MgLevel * len(vals))()
-        for i, (lev, v) in enumerate(zip(self.p.levels, vals)):
+    def lattice_levels(self, vals, vals32=None, dense=None):
+        """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
+        level, whose solve becomes one dense product (diffhe_mg_level.dense_inv)."""
+        nl = len(vals) if dense is None else dense[0] + 1
+        arr = (_hip.MgLevel * nl)()
+        for i, (lev, v) in enumerate(zip(self.p.levels[:nl], vals[:nl])):
             arr[i].nx, arr[i].ny, arr[i].nd, arr[i].reserved = lev.nx, lev.ny, lev.nd, 0
             arr[i].vals, arr[i].is_bc = v.data_ptr(), lev.is_bc.data_ptr()
             arr[i].vals32 = vals32[i].data_ptr() if vals32 is not None and vals32[i] is not None else None
+            arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None):
         p, L = self.p, self.L
-        arr = self.lattice_levels(vals, vals32)
-        nl = len(vals)
+        arr = self.lattice_levels(vals, vals32, dense)
+        nl = len(arr)
         x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
         work = torch.empty(L.diffhe_lattice_pcg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
@@ -441,7 +445,14 @@ def _solve_forward(solver, kappa, f):
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
         # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
         vals32 = [v.float() for v in vals] if (Bv != 1 and mg.get("fp32")) else None
-        x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32)
+        # factored operator (one plan-constant unit matrix per level): the levels from ~33^2 nodes down are replaced
+        # by ONE dense product with the cached inverse of that level's matrix (they cost ~45 launch-bound launches
+        # per cycle); wave-sized batches only
+        dense = None
+        if mode == K_SAMPLE and closed_ and Bv == 1 and Bp >= 64 and mg.get("dense_coarse", 1):
+            dense = plan.dense_coarse(vals, bool(mg.get("fp32")))
+        x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense)
+        ctx.dense = dense
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
         info.err_est = float(eng.last_est[:B].max())
@@ -507,7 +518,7 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         vals, x, Bp, Bv, scale = ctx.saved
         rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
         if ctx.path == "lattice-mgpcg":
-            lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32)
+            lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense)
             info.adj_err_est = float(eng.last_est[:B].max())
         elif ctx.path == "ell-amgpcg":    # same preconditioner (and the saved per-sample coarse operators) as forward
             lam, its, bad, relres = eng.amg_pcg(ctx.amg_hier, rhs, Bp, Bv, ctx.amg)

@@ -230,6 +230,10 @@ typedef struct diffhe_mg_level {
   const unsigned char* is_bc;  /* (n) */
   const float* vals32;         /* optional fp32 copy of vals (NULL = none): read by the fp32-stored
                                   V-cycle when Bv == Bp; the outer CG always applies the fp64 values */
+  const void* dense_inv;       /* LAST level only, Bv == 1, optional: dense inverse (n, n) row-major of this level's
+                                  matrix (identity rows -> zero rows), fp32 when the V-cycle is stored fp32 else
+                                  fp64.  The coarsest-level solve is then ONE dense product per cycle (scaled by
+                                  1 / scale[b]) instead of the Chebyshev iteration; NULL = Chebyshev */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
