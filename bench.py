@@ -331,12 +331,13 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
         Ap = torch.empty_like(x)
         ab = torch.rand(2, Bp, dtype=torch.float64, device=dev)
         part = torch.empty(L.diffhe_lattice_blocks(n, Bp) * Bp, dtype=torch.float64, device=dev)
+        # x = NULL: the variant the solver launches (directions kept in a ring, x formed once at the end)
         dur = time_launch(lambda: _hip.check(L.diffhe_lattice_cg_step(
-            arr, Bv, _hip.ptr(scale), _hip.ptr(z), int(f32), _hip.ptr(p_in), _hip.ptr(p_out), _hip.ptr(x),
-            _hip.ptr(ab[0]), _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), Bp, st), "diffhe_lattice_cg_step"))
+            arr, Bv, _hip.ptr(scale), _hip.ptr(z), int(f32), _hip.ptr(p_in), _hip.ptr(p_out), None,
+            None, _hip.ptr(ab[1]), 0, _hip.ptr(Ap), _hip.ptr(part), Bp, st), "diffhe_lattice_cg_step"))
         zb = 4.0 if f32 else 8.0
-        alg_bytes = (3 * zb + 24.0) * n * Bp  # read z, p, x; write p, Ap, x (matrix batch-shared: amortised)
-        kname = "dia_strip_kernel<M_APPLY,F_PUPD> (fused CG step: p-update + x-update + operator apply + dot)"
+        alg_bytes = (3 * zb + 8.0) * n * Bp  # read z, p_old; write p, Ap (matrix batch-shared: amortised; x untouched)
+        kname = "dia_strip_kernel<M_APPLY,F_PUPD> (fused CG step: p = z + beta p, Ap = A p, p.Ap)"
         # second kernel family: one weighted-Jacobi sweep of the V-cycle on the fine level, fp64 storage
         rhs = torch.rand((n, Bp), dtype=torch.float64, device=dev)
         dur_j = time_launch(lambda: _hip.check(L.diffhe_lattice_smooth(

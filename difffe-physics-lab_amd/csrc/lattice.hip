@@ -158,13 +158,17 @@ enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
 //              columns 2 J0 - 1 .. 2 J0 + 2 CW - 1 that feed the wave's CW coarse columns (one fine
 //              column is shared with -- and recomputed by -- each neighbour strip) and the tile the
 //              fine rows 2 I0 - 1 .. 2 I1 - 1 of the coarse rows I0 .. I1 - 1.
-enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2, F_RESTRICT = 3 };
+enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2, F_RESTRICT = 3, F_PUPD_NX = 4 };
+// F_PUPD_NX: F_PUPD without the iterate update (the solver's form: x is assembled from the kept directions at the
+// end); a compile-time variant so that the x stream costs neither registers nor instructions
+constexpr bool is_pupd(int fuse) { return fuse == F_PUPD || fuse == F_PUPD_NX; }
 
 struct Extra {
   const void* a0;           // F_PROLONG: coarse correction e (TA);  F_PUPD: z (TA)
   const void* p_in;         // F_PUPD: previous search direction, stored as TA (the type of z)
   void* p_out;              // F_PUPD: new search direction, stored as TA
-  double* x;                // F_PUPD: iterate, updated in place
+  double* x;                // F_PUPD: iterate, updated in place (NULL: left alone -- the solver keeps its directions
+                            //   and forms x once at the end, pcg_finish_kernel)
   const double* alpha;      // F_PUPD: per-sample alpha of the previous iteration
   const double* beta;       // F_PUPD
   int first;                // F_PUPD: first iteration (p = z, nothing pending)
@@ -225,14 +229,14 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const double inv_omega_in = XFROMB ? 1.0 / omega_in : 0.0;
   const double sub_fac = (MODE == M_APPLY && FUSE == F_NONE && ex.sub && ex.sub_scale) ? ex.sub_scale[b] : 1.0;
   const double rsc = (MODE == M_RESID && FUSE == F_NONE && ex.r32 && ex.rscale) ? ex.rscale[b] : 1.0;
-  const double beta = (FUSE == F_PUPD && !ex.first) ? ex.beta[b] : 0.0;
-  const double alpha_prev = (FUSE == F_PUPD && !ex.first) ? ex.alpha[b] : 0.0;
+  const double beta = (is_pupd(FUSE) && !ex.first) ? ex.beta[b] : 0.0;
+  const double alpha_prev = (FUSE == F_PUPD && !ex.first && ex.x) ? ex.alpha[b] : 0.0;  // alpha is NULL when x is
   const TA* __restrict__ aux = (const TA*)ex.a0;
   // F_PUPD row pointers at (row, c0w), advanced with the others
-  const TA* __restrict__ pz = (FUSE == F_PUPD) ? aux + i0 * Bp : nullptr;
-  const TA* __restrict__ ppi = (FUSE == F_PUPD) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
-  TA* __restrict__ ppo = (FUSE == F_PUPD) ? (TA*)ex.p_out + i0 * Bp : nullptr;
-  double* __restrict__ pxx = (FUSE == F_PUPD) ? ex.x + i0 * Bp : nullptr;
+  const TA* __restrict__ pz = (is_pupd(FUSE)) ? aux + i0 * Bp : nullptr;
+  const TA* __restrict__ ppi = (is_pupd(FUSE)) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
+  TA* __restrict__ ppo = (is_pupd(FUSE)) ? (TA*)ex.p_out + i0 * Bp : nullptr;
+  double* __restrict__ pxx = (FUSE == F_PUPD && ex.x) ? ex.x + i0 * Bp : nullptr;  // NULL: the iterate is not touched
 
   // `row` is the grid row being loaded; xrow / d0row point at (row, c0w); roff = offset of that
   // row from the current one in vector elements
@@ -252,7 +256,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 #pragma unroll
     for (int q = 0; q < RW + 2; ++q) {
       double v;
-      if (FUSE == F_PUPD) {
+      if (is_pupd(FUSE)) {
         const i64 o = roff + (i64)dq[q] * Bp;
         v = (double)(pz + o)[lb];
         if (!ex.first) v += beta * (double)(ppi + o)[lb];
@@ -338,7 +342,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         if (po) {
           // CG-step streams (Ap, p, x) are touched once per iteration, 1-2 GB each: nontemporal accesses keep them
           // from evicting the halo columns and the V-cycle's vectors from L2 / Infinity Cache (fused step -4 %)
-          if (FUSE == F_PUPD) __builtin_nontemporal_store((TV)y, &(po + o)[lb]);
+          if (is_pupd(FUSE)) __builtin_nontemporal_store((TV)y, &(po + o)[lb]);
           else (po + o)[lb] = (TV)y;
         }
         if (FUSE == F_NONE && ex.dotv) {  // bilinear form lam^T (A x + add): dL/dkappa of a factored operator
@@ -347,9 +351,9 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         } else {
           s += y * xc[q];
         }
-        if (FUSE == F_PUPD) {  // store the new direction; apply the pending x += alpha_prev * p_old
+        if (is_pupd(FUSE)) {  // store the new direction; apply the pending x += alpha_prev * p_old
           __builtin_nontemporal_store((TA)xc[q], &(ppo + o)[lb]);
-          if (!ex.first) {
+          if (FUSE == F_PUPD && !ex.first && pxx) {
             double* xa_ = &(pxx + o)[lb];
             __builtin_nontemporal_store(__builtin_nontemporal_load(xa_) + alpha_prev * (double)(ppi + o)[lb], xa_);
           }
@@ -423,7 +427,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     px += rowX;
     if (pb) pb += rowX;
     if (po) po += rowX;
-    if (FUSE == F_PUPD) { pz += rowX; ppi += rowX; ppo += rowX; pxx += rowX; }
+    if (is_pupd(FUSE)) { pz += rowX; ppi += rowX; ppo += rowX; if (FUSE == F_PUPD && pxx) pxx += rowX; }
   }
   return s;
 }
@@ -437,8 +441,9 @@ __device__ inline int xcd_tile(int x, int gx) {
   return k * q + (k < rem ? k : rem) + j;
 }
 
-template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW>
-__global__ __launch_bounds__(256) void dia_strip_kernel(Level L, const double* __restrict__ scale,
+template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
+          int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void dia_strip_kernel(Level L, const double* __restrict__ scale,
                                                          const TV* __restrict__ xin, const TV* __restrict__ bvec,
                                                          TV* __restrict__ out, double omega, double omega_in,
                                                          Extra ex, double* __restrict__ part, int Bp, int ncb,
@@ -519,7 +524,7 @@ inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols) {
   return g;
 }
 
-template <typename TV, int MODE, bool XFROMB, int FUSE = F_NONE, typename TA = TV, int RW = kStripCols>
+template <typename TV, int MODE, bool XFROMB, int FUSE = F_NONE, typename TA = TV, int RW = kStripCols, int MINW = 1>
 void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, const TV* bvec, TV* out,
                   double omega, double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st,
                   const Extra& ex = Extra{}) {
@@ -531,13 +536,13 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
     double bpn;
     if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * tv + (FUSE == F_PROLONG ? 0.25 * tv : 0.0);
     else if (MODE == M_RESID) bpn = 2.0 * tv + (FUSE == F_RESTRICT ? 0.25 * tv : (out ? tv : 0.0) + (ex.r32 ? 4.0 : 0.0));
-    else if (FUSE == F_PUPD) bpn = ex.first ? 2.0 * ta + 8.0 : 3.0 * ta + 24.0;
+    else if (is_pupd(FUSE)) bpn = ex.first ? 2.0 * ta + 8.0 : 3.0 * ta + 8.0 + ((FUSE == F_PUPD && ex.x) ? 16.0 : 0.0);
     else bpn = tv + (out ? tv : 0.0) + (ex.dotv ? 8.0 : 0.0);
     if (Bv != 1) bpn += L.nd * (m32 ? 4.0 : 8.0);
     diffhe::account(bpn * (double)L.n * Bp);
   }
 #define STRIP(ND_, SH_, TM_)                                                                                       \
-  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW>), grid, dim3(256), 0, st, L,   \
+  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW, MINW>), grid, dim3(256), 0, st, L,   \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
   if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true, double); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
@@ -817,15 +822,23 @@ __global__ __launch_bounds__(256) void pcg_axpy_kernel(const double* __restrict_
 // V-cycle's own convergence factor (< 0.3) for no extra pass.
 template <typename TP>
 __global__ __launch_bounds__(256) void pcg_finish_kernel(const double* __restrict__ alpha, const TP* __restrict__ p,
+                                                          long long slot_stride, int j0, int count, int n_slots,
                                                           const TP* __restrict__ z, const double* __restrict__ rs,
                                                           double* __restrict__ x, int n, int Bp) {
+  // x += sum_{j = j0 .. j0 + count - 1} alpha_j p_j (+ z / rs): direction j lives in slot j % n_slots of `p`, its
+  // step lengths in row j % n_slots of `alpha` (0 for samples that had stopped)
   const NodeMap nm = node_map(Bp);
-  const double a = p ? alpha[nm.b] : 0.0;
-  const double zi = rs ? 1.0 / rs[nm.b] : 1.0;   // rs is a power of two: exact
+  const double zi = z ? (rs ? 1.0 / rs[nm.b] : 1.0) : 0.0;   // rs is a power of two: exact
+  double a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = k < count ? alpha[(long long)((j0 + k) % n_slots) * Bp + nm.b] : 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    double v = x[o] + zi * (double)z[o];
-    if (p) v += a * (double)p[o];
+    double v = x[o];
+    if (z) v += zi * (double)z[o];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < count) v += a[k] * (double)p[(long long)((j0 + k) % n_slots) * slot_stride + o];
     x[o] = v;
   }
 }
@@ -1371,7 +1384,7 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = lgrid(H.lev[0].n, Bp).x;
   (void)nblk;
-  return carve(H, nullptr, false) + 4 * nb + 2LL * kPartBlocks * Bp + 16LL * Bp + 64;  // fp64 layout is the larger
+  return carve(H, nullptr, false) + 5 * nb + 2LL * kPartBlocks * Bp + 32LL * Bp + 64;  // fp64 layout is the larger
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
@@ -1393,10 +1406,15 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;
+  // Search directions.  Fused loop: the iterate is NOT touched inside the loop (that cost 16 of the fused step's 36
+  // bytes per node); the directions p_j stay in a ring of slots (6 fp32 / 3 fp64 vectors in these 3 nb doubles) with
+  // their step lengths alpha_j, and x += sum_j alpha_j p_j is formed when the ring is full or the solve ends.
+  // Unfused loop (small meshes / batches): one fp64 p in the same region, x updated every iteration.
   double* p = r + nb;
-  double* Ap = p + nb;
-  double* p2 = Ap + nb;  // second direction buffer: the fused apply reads p_old with halos, so p ping-pongs
-  double* partA = p2 + nb;
+  const int n_slots = f32 ? 6 : 3;
+  const long long slot_stride = nb;              // in elements of the stored type: fp32 slots are nb floats apart
+  double* Ap = p + 3 * nb;
+  double* partA = Ap + nb;
   double* partB = partA + (long long)kPartBlocks * Bp;
   double* sc = partB + (long long)kPartBlocks * Bp;
   PcgScalars S;
@@ -1412,6 +1430,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.energy = sc + 12 * Bp;
   S.est = err_est ? err_est : sc + 13 * Bp;
   S.rr = sc + 14 * Bp;
+  double* alpha_ring = sc + 16 * Bp;              // n_slots (<= 6) rows of Bp step lengths
+  double* const alpha_single = S.alpha;
   // tol_energy is asked of the FINAL iterate, which receives one more multigrid correction after the decision
   // (pcg_finish_kernel): the CG iterate's own estimate may be 1 / 0.3 of it (0.3: a cautious bound of the V(2,2)
   // cycle's convergence factor; measured reductions of the nodal error by that step: 5-8x)
@@ -1450,9 +1470,25 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
   // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
+  // development knob: strip width / occupancy of the fused CG step (gpurun_out/r2l/variants.txt)
+  static const int pupd_variant = getenv("DIFFHE_PUPD_VARIANT") ? atoi(getenv("DIFFHE_PUPD_VARIANT")) : 0;
   const StripGeom g0 = strip_geom(L0, Bp, kPupdCols);
   const bool fused = g0.use;
   const void* z = nullptr;
+  int it = 0, flushed = 0;       // iterations done / directions already folded into x (fused loop)
+  // x += sum_{j = flushed .. it-1} alpha_j p_j  (+ z / rs at the end of the solve: pcg_finish_kernel)
+  auto flush_directions = [&](bool with_z) {
+    const int count = it - flushed;
+    if (count == 0 && !with_z) return;
+    const double bytes = 16.0 + (f32 ? 4.0 : 8.0) * (count + (with_z ? 1 : 0));
+    if (f32)
+      LAUNCH(bytes, pcg_finish_kernel<float>, n, (const double*)alpha_ring, (const float*)(const void*)p, slot_stride,
+             flushed, count, n_slots, with_z ? (const float*)z : (const float*)nullptr, (const double*)S.rs, x, n, Bp);
+    else
+      LAUNCH(bytes, pcg_finish_kernel<double>, n, (const double*)alpha_ring, (const double*)p, slot_stride, flushed, count,
+             n_slots, with_z ? (const double*)z : (const double*)nullptr, (const double*)nullptr, x, n, Bp);
+    flushed = it;
+  };
   auto precondition = [&](int first) {
     if (f32) z = vcycle<float>(H, (const float*)r32, partB, &nbz, st);
     else z = vcycle<double>(H, (const double*)r, partB, &nbz, st);
@@ -1464,15 +1500,29 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
         (void)hipEventRecord(g_prof.e0, st);
         g_prof.have = true;
       }
+      if (it - flushed == n_slots) flush_directions(false);   // ring full: fold everything so far into x
+      const size_t esz = f32 ? sizeof(float) : sizeof(double);
+      char* ring = (char*)p;
       Extra ex{};
-      ex.a0 = z; ex.p_in = p; ex.p_out = p2; ex.x = x; ex.alpha = S.alpha; ex.beta = S.beta; ex.first = first;
-      if (f32)
-        launch_strip<double, M_APPLY, false, F_PUPD, float, kPupdCols>(L0, Bv, scale, (const double*)nullptr,
-                                                            (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
+      ex.a0 = z;
+      ex.p_in = ring + (size_t)((it + n_slots - 1) % n_slots) * slot_stride * esz;
+      ex.p_out = ring + (size_t)(it % n_slots) * slot_stride * esz;
+      ex.x = nullptr;            // deferred (flush_directions)
+      ex.alpha = nullptr; ex.beta = S.beta; ex.first = first;
+#define NXV(RW_, MINW_)                                                                                               \
+  launch_strip<double, M_APPLY, false, F_PUPD_NX, float, RW_, MINW_>(L0, Bv, scale, (const double*)nullptr,                \
+                                                                      (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex)
+      if (f32) {
+        // 72 VGPRs (18 spilled), 7 waves per SIMD: 1.16 ms against 1.28 at the compiler's own 85 / 5; 8-column strips
+        // (142 VGPRs) 1.96, 2-column strips at 8 waves 1.27, 6 or 8 waves 1.25 / 1.18 (same box, gpurun_out/r2l/variants*.txt).
+        // The same cap on the V-cycle's strip kernels (already 6-7 waves) made them slower: -2...-6 % end to end.
+        if (pupd_variant == 5) NXV(4, 1); else NXV(4, 7);
+      }
+#undef NXV
       else
-        launch_strip<double, M_APPLY, false, F_PUPD, double, kPupdCols>(L0, Bv, scale, (const double*)nullptr,
-                                                             (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
-      double* t = p; p = p2; p2 = t;
+        launch_strip<double, M_APPLY, false, F_PUPD_NX, double, kPupdCols>(L0, Bv, scale, (const double*)nullptr,
+                                                                (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
+      S.alpha = alpha_ring + (long long)(it % n_slots) * Bp;   // alpha_it goes next to p_it
       nba = g0.ncb * g0.nrc;
       if (g_prof.on && !first) (void)hipEventRecord(g_prof.e1, st);
     } else {
@@ -1513,7 +1563,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   rc = diffhe::check_launch();
   if (rc) return rc;
 
-  int it = 0, n_active = -1;
+  int n_active = -1;
   while (it < max_iter) {
     apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
@@ -1539,16 +1589,11 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     }
     if (n_active == 0) break;
   }
-  {  // flush the pending x += alpha p of the fused loop and add the final V-cycle's correction z (pcg_finish_kernel)
-    const bool pend = fused && it > 0;
-    // fp32 mode: the fused loop stores p as fp32 in the p / p2 buffers; the unfused loop keeps an fp64 p (x is current)
-    if (f32)
-      LAUNCH(pend ? 24.0 : 20.0, pcg_finish_kernel<float>, n, (const double*)S.alpha,
-             pend ? (const float*)(const void*)p : (const float*)nullptr, (const float*)z, (const double*)S.rs, x, n, Bp);
-    else
-      LAUNCH(pend ? 32.0 : 24.0, pcg_finish_kernel<double>, n, (const double*)S.alpha,
-             pend ? (const double*)p : (const double*)nullptr, (const double*)z, (const double*)nullptr, x, n, Bp);
-  }
+  // fold the directions still in the ring into x and add the final V-cycle's correction z (pcg_finish_kernel);
+  // the unfused loop kept x current: only z is due there
+  if (!fused) flushed = it;
+  flush_directions(true);
+  S.alpha = alpha_single;
   nba = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
   SCALAR(S_RELRES, partA, nba);
   rc = diffhe::check_launch();
@@ -1596,7 +1641,7 @@ extern "C" int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, con
 extern "C" int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z,
                                       int z_fp32, const void* p_in, void* p_out, double* x, const double* alpha,
                                       const double* beta, int first, double* Ap, double* part, int Bp, void* stream) {
-  if (!z || !p_out || !x || !Ap || !part || (!first && (!p_in || !alpha || !beta))) return DIFFHE_E_BADARG;
+  if (!z || !p_out || !Ap || !part || (!first && (!p_in || !beta || (x && !alpha)))) return DIFFHE_E_BADARG;
   Hier H;
   const double w1 = 0.8;
   int rc = fill_hier(H, level, 1, Bv, Bp, scale, &w1, 1, 1);
@@ -1606,14 +1651,19 @@ extern "C" int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, cons
   Extra ex{};
   ex.a0 = z; ex.p_in = p_in; ex.p_out = p_out; ex.x = x; ex.alpha = alpha; ex.beta = beta; ex.first = first;
   hipStream_t st = (hipStream_t)stream;
-  if (z_fp32)
-    launch_strip<double, M_APPLY, false, F_PUPD, float, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,
-                                                                   (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st,
-                                                                   ex);
-  else
-    launch_strip<double, M_APPLY, false, F_PUPD, double, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,
-                                                                    (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st,
-                                                                    ex);
+#define CGSTEP(FUSE_, TA_)                                                                                          \
+  launch_strip<double, M_APPLY, false, FUSE_, TA_, kPupdCols>(H.lev[0], Bv, scale, (const double*)nullptr,              \
+                                                              (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st, ex)
+  if (x) {
+    if (z_fp32) CGSTEP(F_PUPD, float); else CGSTEP(F_PUPD, double);
+  } else {
+    if (z_fp32)   // the solver's instantiation (7 waves per SIMD)
+      launch_strip<double, M_APPLY, false, F_PUPD_NX, float, kPupdCols, 7>(H.lev[0], Bv, scale, (const double*)nullptr,
+                                                                          (const double*)nullptr, Ap, 0.0, 0.0, part, Bp, g, st, ex);
+    else
+      CGSTEP(F_PUPD_NX, double);
+  }
+#undef CGSTEP
   return diffhe::check_launch();
 }
 

@@ -287,6 +287,9 @@ int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* sc
  *   Ap = A p_out;  part = block partials of p_out . Ap.   z, p_in and p_out are (n, Bp) fp32
  *   (z_fp32 != 0) or fp64: the search direction is stored in the precision of the preconditioner
  *   output; x, Ap and the dots are always fp64 and use the STORED p, so r = b - A x stays exact.
+ * x == NULL: the iterate is left alone -- the form diffhe_lattice_pcg_solve launches since ABI v4: it keeps its
+ *   directions in a ring of slots and forms x += sum_j alpha_j p_j when the ring is full / at the end, which takes
+ *   the x read-modify-write (16 of 36 B per node) out of every iteration.
  * p_in and p_out must be different buffers (halo reads of p_in).  DIFFHE_E_TOOBIG below the
  * strip-kernel threshold. */
 int diffhe_lattice_cg_step(const diffhe_mg_level* level, int Bv, const double* scale, const void* z, int z_fp32,

@@ -14,8 +14,8 @@ N, BP = 1025 * 1025, 256
 PASS = 8.0 * N * BP
 # (substring of the kernel name, template-argument pattern) -> (label, algorithmic passes per launch)
 RULES = [
-    ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step (p, x update + A p + dot), z/p fp32", 4.5),
-    ("dia_strip_kernel<double, double, double, 0, 2", "fused CG step, z/p fp64", 6.0),
+    ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step (p = z + beta p, A p, dot; x deferred), z/p fp32", 2.5),
+    ("dia_strip_kernel<double, double, double, 0, 2", "fused CG step, z/p fp64", 4.0),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
     ("dia_strip_kernel<float, float, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp32)", 1.0),
     ("dia_strip_kernel<float, float, double, 1, 3", "residual + restriction, residual never stored (fp32)", 1.125),
@@ -28,6 +28,8 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 2, 1", "prolong + correct + Jacobi sweep (fp64)", 3.25),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, false", "Jacobi sweep (fp64)", 3.0),
     ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),
+    ("pcg_finish_kernel", "x += sum_j alpha_j p_j + V(r) (end of a solve; 5 directions)", 5.0),
+    ("mg_dense_solve_kernel", "dense coarse solve (33^2 level)", 0.0),
     ("pcg_init_kernel", "b.b and fp32 copy of b (x, r are set after the full-multigrid start)", 1.5),
     ("to_node_major_kernel", "(B,n) -> (n,Bp)", 2.0),
     ("to_sample_major_kernel", "(n,Bp) -> (B,n)", 2.0),
