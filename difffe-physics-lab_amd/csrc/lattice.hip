@@ -978,6 +978,41 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
   }
 }
 
+// ---- opt-in timing of the step's main kernels INSIDE the solver loop (bench.py's roofline entries) ----------
+// HIP events on the solve's stream around the fine-level launch of each kernel family, read after the per-iteration
+// stream synchronisation the loop performs anyway.  Per calling thread (the adjoint solves run on autograd's thread
+// and are not sampled); the only hidden state of the library, and only while enabled.
+enum { KP_CGSTEP = 0, KP_UPDATE = 1, KP_FIRST2 = 2, KP_RESTRICT = 3, KP_PROLONG = 4, KP_SWEEP = 5, KP_COUNT = 6 };
+struct KernelProfile {
+  bool on = false;
+  hipEvent_t e0[KP_COUNT] = {}, e1[KP_COUNT] = {};
+  bool have[KP_COUNT] = {};
+  double ms[KP_COUNT] = {};
+  long long n[KP_COUNT] = {};
+};
+thread_local KernelProfile g_kp;
+inline void kp_begin(int id, hipStream_t st) {
+  if (g_kp.on) (void)hipEventRecord(g_kp.e0[id], st);
+}
+inline void kp_end(int id, hipStream_t st) {
+  if (g_kp.on) {
+    (void)hipEventRecord(g_kp.e1[id], st);
+    g_kp.have[id] = true;
+  }
+}
+inline void kp_collect() {  // call with the stream idle: every recorded event has completed
+  if (!g_kp.on) return;
+  for (int id = 0; id < KP_COUNT; ++id) {
+    if (!g_kp.have[id]) continue;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, g_kp.e0[id], g_kp.e1[id]) == hipSuccess) {
+      g_kp.ms[id] += ms;
+      g_kp.n[id] += 1;
+    }
+    g_kp.have[id] = false;
+  }
+}
+
 // ---- host-side hierarchy --------------------------------------------------------------------
 constexpr int kMaxLevels = 16;
 
@@ -1014,8 +1049,10 @@ int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, doub
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
   if (g.use && xin) {
+    if (l == 0) kp_begin(KP_SWEEP, st);
     launch_strip<TV, M_JACOBI, false, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part,
                                                                    H.Bp, g, st);
+    if (l == 0) kp_end(KP_SWEEP, st);
     return g.ncb * g.nrc;
   }
   LAUNCH((xin ? 3 : 2) * sizeof(TV) + MATB(L), dia_jacobi_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, xin, xout, omega, part, H.Bp);
@@ -1029,8 +1066,10 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
   const Level& L = H.lev[l];
   const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
   if (g.use) {
+    if (l == 0) kp_begin(KP_FIRST2, st);
     launch_strip<TV, M_JACOBI, true, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0,
                                                                   part, H.Bp, g, st);
+    if (l == 0) kp_end(KP_FIRST2, st);
     *result = xa;
     return g.ncb * g.nrc;
   }
@@ -1225,8 +1264,10 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         Extra ex{};
         ex.cW = C.W;
         ex.bc = C.bc;
+        if (l == 0) kp_begin(KP_RESTRICT, st);
         launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, (const TV*)a, rhs[l],
                                                                        (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
+        if (l == 0) kp_end(KP_RESTRICT, st);
       } else {
         op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
         LAUNCH(((double)L.n / C.n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
@@ -1245,9 +1286,11 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
+      if (l == 0) kp_begin(KP_PROLONG, st);
       launch_strip<TV, M_JACOBI, false, F_PROLONG, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2,
                                                                           H.omega[H.nu - 1], 0.0,
                                                                           lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      if (l == 0) kp_end(KP_PROLONG, st);
       if (lastsweep && rz_blocks) *rz_blocks = g.ncb * g.nrc;
       TV* t = a; a = b2; b2 = t;
       s0 = 1;
@@ -1298,31 +1341,28 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
 
 }  // namespace
 
-// Opt-in timing of the dominant kernel INSIDE the solver loop (bench.py's roofline entry): HIP events around every
-// fused CG-step launch, read after the per-iteration stream synchronisation the loop performs anyway.
-namespace {
-struct StepProfile {
-  bool on = false;
-  bool have = false;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  double ms = 0.0;
-  long long launches = 0;
-};
-thread_local StepProfile g_prof;
-}  // namespace
-
 extern "C" int diffhe_lattice_pcg_profile(int enable, double* total_ms, long long* launches) {
-  if (total_ms) *total_ms = g_prof.ms;
-  if (launches) *launches = g_prof.launches;
+  if (total_ms) *total_ms = g_kp.ms[KP_CGSTEP];
+  if (launches) *launches = g_kp.n[KP_CGSTEP];
   if (enable >= 0) {
-    if (enable && !g_prof.e0) {
-      if (hipEventCreate(&g_prof.e0) != hipSuccess || hipEventCreate(&g_prof.e1) != hipSuccess) return DIFFHE_E_LAUNCH;
+    if (enable && !g_kp.e0[0]) {
+      for (int id = 0; id < KP_COUNT; ++id)
+        if (hipEventCreate(&g_kp.e0[id]) != hipSuccess || hipEventCreate(&g_kp.e1[id]) != hipSuccess) return DIFFHE_E_LAUNCH;
     }
-    g_prof.on = enable != 0;
-    g_prof.ms = 0.0;
-    g_prof.launches = 0;
-    g_prof.have = false;
+    g_kp.on = enable != 0;
+    for (int id = 0; id < KP_COUNT; ++id) {
+      g_kp.ms[id] = 0.0;
+      g_kp.n[id] = 0;
+      g_kp.have[id] = false;
+    }
   }
+  return DIFFHE_OK;
+}
+
+extern "C" int diffhe_lattice_kernel_profile(int id, double* total_ms, long long* launches) {
+  if (id < 0 || id >= KP_COUNT) return DIFFHE_E_BADARG;
+  if (total_ms) *total_ms = g_kp.ms[id];
+  if (launches) *launches = g_kp.n[id];
   return DIFFHE_OK;
 }
 
@@ -1496,10 +1536,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   };
   auto apply_step = [&](int first) {
     if (fused) {
-      if (g_prof.on && !first) {  // the first step of a solve (p = z, nothing pending) moves fewer bytes: not timed
-        (void)hipEventRecord(g_prof.e0, st);
-        g_prof.have = true;
-      }
+      if (!first) kp_begin(KP_CGSTEP, st);  // the first step of a solve (p = z) moves fewer bytes: not timed
       if (it - flushed == n_slots) flush_directions(false);   // ring full: fold everything so far into x
       const size_t esz = f32 ? sizeof(float) : sizeof(double);
       char* ring = (char*)p;
@@ -1524,7 +1561,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
                                                                 (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex);
       S.alpha = alpha_ring + (long long)(it % n_slots) * Bp;   // alpha_it goes next to p_it
       nba = g0.ncb * g0.nrc;
-      if (g_prof.on && !first) (void)hipEventRecord(g_prof.e1, st);
+      if (!first) kp_end(KP_CGSTEP, st);
     } else {
       if (f32) LAUNCH(first ? 12.0 : 20.0, pcg_update_p_kernel<float>, n, (const float*)z, (const double*)S.beta, p, first, n, Bp);
       else LAUNCH(first ? 16.0 : 24.0, pcg_update_p_kernel<double>, n, (const double*)z, (const double*)S.beta, p, first, n, Bp);
@@ -1567,8 +1604,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   while (it < max_iter) {
     apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
+    kp_begin(KP_UPDATE, st);
     LAUNCH(24.0 + (r32 ? 4.0 : 0.0) + (fused ? 0.0 : 24.0), pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
            r, r32, (const double*)S.rs, partA, n, Bp);
+    kp_end(KP_UPDATE, st);
     SCALAR(S_CONV, partA, nblk);
     ++it;
     // z = V(r) and r.z: the new search direction's ingredients AND the energy-norm error estimate of the iterate;
@@ -1579,14 +1618,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     rc = diffhe::check(hipStreamSynchronize(st));
     if (rc) return rc;
     n_active = status_host[2];
-    if (g_prof.on && g_prof.have) {  // the stream is idle here: both events have completed
-      float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, g_prof.e0, g_prof.e1) == hipSuccess) {
-        g_prof.ms += ms;
-        g_prof.launches += 1;
-      }
-      g_prof.have = false;
-    }
+    kp_collect();  // the stream is idle here
     if (n_active == 0) break;
   }
   // fold the directions still in the ring into x and add the final V-cycle's correction z (pcg_finish_kernel);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P,
                                       _P, _P, _P, _P]),
     "diffhe_lattice_pcg_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
+    "diffhe_lattice_kernel_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_lattice_blocks": (_I, [_I, _I]),
     "diffhe_lattice_apply": (_I, [_LV, _I, _P, _P, _P, _P, _I, _P]),
     "diffhe_lattice_smooth": (_I, [_LV, _I, _P, _P, _P, _P, _D, _I, _P]),

@@ -274,6 +274,10 @@ int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv
  * library, and only in this mode) and resets the counters, 0 stops, < 0 only reads.  The events bracket each launch
  * on the solve's stream and are read after the loop's per-iteration synchronisation.  Returns the totals so far. */
 int diffhe_lattice_pcg_profile(int enable, double* total_ms, long long* launches);
+/* The same events exist for the other main kernels of an iteration (fine-level launches only); read-only access:
+ *   id 0 fused CG step (full-work launches), 1 residual update r -= alpha Ap, 2 first two sweeps from 0,
+ *      3 residual + restriction, 4 prolongation + sweep, 5 sweep.   enable / reset through diffhe_lattice_pcg_profile. */
+int diffhe_lattice_kernel_profile(int id, double* total_ms, long long* launches);
 /* Single kernels of that loop, exposed for timing/tests: y = A x (+ x.y block partials in
  * `part`, diffhe_lattice_blocks(n, Bp) * Bp doubles) and one damped-Jacobi sweep
  * xout = xin + omega (rhs - A xin)/D  (xin NULL = 0). */
