@@ -1168,6 +1168,28 @@ __global__ __launch_bounds__(256) void mg_dense_solve_kernel(int n, const TV* __
   }
 }
 
+// The same product for batches below a wave (Bp = 1 .. 32, the unbatched call shape of the reference): one wave per
+// row, lanes over the columns j, a wave reduction per sample.
+template <typename TV>
+__global__ __launch_bounds__(64) void mg_dense_small_kernel(int n, const TV* __restrict__ inv,
+                                                             const double* __restrict__ scale,
+                                                             const TV* __restrict__ rhs, TV* __restrict__ x,
+                                                             double* __restrict__ part, int Bp) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const TV* __restrict__ row = inv + (i64)i * n;
+  for (int b = 0; b < Bp; ++b) {
+    double s = 0.0;
+    for (int j = lane; j < n; j += kWave) s += (double)row[j] * (double)rhs[(i64)j * Bp + b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) {
+      const double xo = (scale ? 1.0 / scale[b] : 1.0) * s;
+      x[(i64)i * Bp + b] = (TV)xo;
+      if (part) part[(i64)i * Bp + b] = (double)rhs[(i64)i * Bp + b] * xo;   // one partial row per matrix row
+    }
+  }
+}
+
 // Coarsest-level solve: Chebyshev semi-iteration for D^-1 A with the spectrum bounds of the P1 Laplacian
 // on an nx x ny lattice, lambda in [ (1 - cos(pi/nx))/2 + (1 - cos(pi/ny))/2 , 2 ]; the lower bound is halved
 // for safety (below it the polynomial stays < 1, it only damps less).  The degree follows from the size, so a
@@ -1176,13 +1198,19 @@ __global__ __launch_bounds__(256) void mg_dense_solve_kernel(int n, const TV* __
 template <typename TV>
 TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks, hipStream_t st) {
   const Level& L = H.lev[l];
-  if (L.inv && H.Bv == 1 && H.Bp >= kWave) {  // dense inverse of the shared level matrix: one launch
-    constexpr int RPB = 4;
-    const dim3 grid((L.n + RPB - 1) / RPB, H.Bp / kWave);
+  if (L.inv && H.Bv == 1 && L.n <= kPartBlocks) {  // dense inverse of the shared level matrix: one launch
     diffhe::account(2.0 * sizeof(TV) * (double)L.n * H.Bp);
-    hipLaunchKernelGGL((mg_dense_solve_kernel<TV, RPB>), grid, dim3(256), 0, st, L.n, (const TV*)L.inv, H.scale, rhs,
-                       (TV*)H.xa[l], part, H.Bp);
-    if (nblocks) *nblocks = grid.x;
+    if (H.Bp >= kWave) {
+      constexpr int RPB = 4;
+      const dim3 grid((L.n + RPB - 1) / RPB, H.Bp / kWave);
+      hipLaunchKernelGGL((mg_dense_solve_kernel<TV, RPB>), grid, dim3(256), 0, st, L.n, (const TV*)L.inv, H.scale, rhs,
+                         (TV*)H.xa[l], part, H.Bp);
+      if (nblocks) *nblocks = grid.x;
+    } else {
+      hipLaunchKernelGGL(mg_dense_small_kernel<TV>, dim3(L.n), dim3(64), 0, st, L.n, (const TV*)L.inv, H.scale, rhs,
+                         (TV*)H.xa[l], part, H.Bp);
+      if (nblocks) *nblocks = L.n;
+    }
     return (TV*)H.xa[l];
   }
   const double pi = 3.14159265358979323846;
@@ -1500,6 +1528,29 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const dim3 sgrid((Bp + 63) / 64);
 #define SCALAR(phase, part, nb_) \
   hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
+
+  if (H.nl == 1 && L0.inv && Bv == 1 && !f32 && L0.n <= kPartBlocks) {
+    // DIRECT solve: the whole system is small enough for the dense inverse of its (batch-shared) matrix -- the
+    // reference's own regime (2D meshes up to 32 x 32).  x = (1 / s_b) K_1^{-1} b in one launch, then the true residual.
+    diffhe::account(16.0 * (double)n * Bp);
+    if (Bp >= kWave)
+      hipLaunchKernelGGL((mg_dense_solve_kernel<double, 4>), dim3((n + 3) / 4, Bp / kWave), dim3(256), 0, st, n,
+                         (const double*)L0.inv, scale, b, x, (double*)nullptr, Bp);
+    else
+      hipLaunchKernelGGL(mg_dense_small_kernel<double>, dim3(n), dim3(64), 0, st, n, (const double*)L0.inv, scale, b, x,
+                         (double*)nullptr, Bp);
+    LAUNCH(8.0, pcg_init_kernel, n, b, (double*)nullptr, (double*)nullptr, partA, n, Bp);
+    SCALAR(S_INIT, partA, nblk);                                 // b.b (and the bookkeeping S_RELRES reads)
+    const int nbr = op_residual<double>(H, 0, b, (const double*)x, (double*)nullptr, partA, st);
+    SCALAR(S_RELRES, partA, nbr);
+    rc = diffhe::check(hipMemsetAsync(S.est, 0, sizeof(double) * Bp, st));
+    if (rc) return rc;
+    rc = diffhe::check_launch();
+    if (rc) return rc;
+    status_host[0] = 0;
+    status_host[1] = 0;
+    return DIFFHE_OK;
+  }
 
   int nbz = 0, nba = 0;
   const bool light_init = use_fmg && f32;  // the start overwrites x and r; it reads b through r32

@@ -359,15 +359,15 @@ class SolvePlan:
         if not self.is_lattice:
             self.ensure_ell()
 
-    def dense_coarse(self, vals, fp32: bool, max_nodes: int = 1200):
-        """(level index, dense inverse) for the factored lattice operator, or None.  `vals` are the UNIT-kappa
-        symmetric diagonals of every level (plan-constant, so the inverse is built once and cached): the first
-        level with at most `max_nodes` nodes (33 x 33 for power-of-two meshes) is inverted on the host -- identity
-        rows stay identity -- and uploaded in the V-cycle's storage type.  None when the hierarchy has no such
-        level below level 0 (sizes that stop halving early keep the Chebyshev coarse solve)."""
-        idx = next((i for i, lev in enumerate(self.levels) if i > 0 and lev.n <= max_nodes), None)
-        if idx is None:
-            return None
+    def dense_level(self, max_nodes: int = 1200):
+        """Index of the first level with at most `max_nodes` nodes (33 x 33 for power-of-two meshes), or None: the
+        level whose solve a dense inverse replaces for factored operators.  0 = the mesh itself is that small."""
+        return next((i for i, lev in enumerate(self.levels) if lev.n <= max_nodes), None)
+
+    def dense_coarse(self, idx: int, vals, fp32: bool):
+        """(level index, dense inverse) for the factored lattice operator.  `vals` are the UNIT-kappa symmetric
+        diagonals of the levels (plan-constant, so the inverse is built once and cached): level `idx` is inverted on
+        the host -- identity rows stay identity -- and uploaded in the V-cycle's storage type (fp64 for idx 0)."""
         key = (idx, bool(fp32))
         cache = self.__dict__.setdefault("_dense_cache", {})
         if key not in cache:

@@ -186,7 +186,7 @@ class _Engine:
         return x, int(st[0]), int(st[1]), relres
 
     # -- lattice path -----------------------------------------------------------------------
-    def lattice_assemble(self, kappa, mode, B, Bp, factor=True):
+    def lattice_assemble(self, kappa, mode, B, Bp, factor=True, n_levels=None):
         """Per-level symmetric-diagonal operators.  -> (vals per level, Bv, scale, lift, lift_scale).
 
         One scalar kappa per sample is kept factored, K_b = kappa_b * K_1 (solver.py:88,139 are
@@ -198,7 +198,10 @@ class _Engine:
         st = _stream(p.device)
         k = kappa.detach().to(p.device, torch.float64)
         scale = None
-        if mode == K_SCALAR:
+        if mode == K_SCALAR and factor:       # K = kappa K_1: the same factored form, one scale for every sample
+            kl, kse, ksb, Bv = None, 0, 0, 1
+            scale = k.reshape(1).expand(Bp).contiguous()
+        elif mode == K_SCALAR:
             kl, kse, ksb, Bv = k.reshape(1).contiguous(), 0, 0, 1
         elif mode == K_SAMPLE and factor:
             kl, kse, ksb, Bv = None, 0, 0, 1
@@ -216,7 +219,7 @@ class _Engine:
                 kl[:, B:] = 1.0
             kse, ksb, Bv = Bp, 1, Bp
         vals, lift = [], None
-        for li, lev in enumerate(p.levels):
+        for li, lev in enumerate(p.levels[:n_levels] if n_levels else p.levels):
             if li > 0 and mode in (K_ELEM, K_SAMPLE_ELEM):   # coarse kappa = mean of the 4 children
                 kc = torch.empty((lev.m, Bv), dtype=torch.float64, device=p.device)
                 prev = p.levels[li - 1]
@@ -440,19 +443,27 @@ def _solve_forward(solver, kappa, f):
         # ill-conditioned enough (cond ~ 1e7 in the randomised sweep) for the last-bit difference between
         # kappa_b (K_1 x) and (sum_e kappa_b k0_e) x to show as 4e-10 in u
         closed_ = plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
-        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_)
+        # factored operator (one plan-constant unit matrix per level, scalar kappa per sample or for all): the levels
+        # from ~33^2 nodes down are replaced by ONE dense product with the cached inverse of that level's matrix (they
+        # cost ~45 launch-bound launches per cycle); a mesh that small as a whole -- the reference's own 2D sizes -- is
+        # solved DIRECTLY by that product (level index 0: no iteration at all)
+        factored = closed_ and mode in (K_SCALAR, K_SAMPLE)
+        didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1)) else None
+        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_,
+                                                                 n_levels=None if didx is None else didx + 1)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
         # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
         vals32 = [v.float() for v in vals] if (Bv != 1 and mg.get("fp32")) else None
-        # factored operator (one plan-constant unit matrix per level): the levels from ~33^2 nodes down are replaced
-        # by ONE dense product with the cached inverse of that level's matrix (they cost ~45 launch-bound launches
-        # per cycle); wave-sized batches only
         dense = None
-        if mode == K_SAMPLE and closed_ and Bv == 1 and Bp >= 64 and mg.get("dense_coarse", 1):
-            dense = plan.dense_coarse(vals, bool(mg.get("fp32")))
+        if didx is not None:
+            if didx == 0:
+                info.path = "lattice-direct"
+                mg = ctx.mg = dict(mg, fp32=0)        # the direct product runs in fp64
+            dense = plan.dense_coarse(didx, vals, bool(mg.get("fp32")))
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense)
         ctx.dense = dense
+        ctx.factored = factored
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
         info.err_est = float(eng.last_est[:B].max())
@@ -517,7 +528,7 @@ def _solve_backward(ctx, gbar, need_k, need_f):
     else:
         vals, x, Bp, Bv, scale = ctx.saved
         rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
-        if ctx.path == "lattice-mgpcg":
+        if ctx.path in ("lattice-mgpcg", "lattice-direct"):
             lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense)
             info.adj_err_est = float(eng.last_est[:B].max())
         elif ctx.path == "ell-amgpcg":    # same preconditioner (and the saved per-sample coarse operators) as forward
@@ -529,9 +540,9 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         info.not_converged += bad
         want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
         dk_nm = dk_sum = None
-        if need_k and ctx.path == "lattice-mgpcg" and mode in (K_SCALAR, K_SAMPLE) and Bv == 1:
+        if need_k and ctx.path in ("lattice-mgpcg", "lattice-direct") and mode in (K_SCALAR, K_SAMPLE) and Bv == 1:
             dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
-            if dk_sum is not None and mode == K_SCALAR:
+            if dk_sum is not None and mode == K_SCALAR and not ctx.factored:
                 dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
         if need_k and dk_sum is None:
             dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e)
@@ -539,7 +550,7 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         dk_elem = None
         if need_k and want_e:
             dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
-        df = eng.to_sample_major(eng.apply_M(lam, Bp, lattice=(ctx.path == "lattice-mgpcg")), B, Bp, n) \
+        df = eng.to_sample_major(eng.apply_M(lam, Bp, lattice=ctx.path.startswith("lattice-")), B, Bp, n) \
             if need_f else None
 
     grad_k = None

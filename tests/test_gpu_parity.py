@@ -65,7 +65,8 @@ def test_gradients_golden(name, assembly, method):
     solver = DifferentiableFESolver(mesh_from(g), kappa, assembly=assembly, method=method)
     u = solver(f)
     if name.startswith("g4"):
-        assert solver.last_info.path == ("lattice-mgpcg" if method == "auto" else "ell-amgpcg") or \
+        # scalar kappa on a closed lattice this small: the direct dense path (no iteration at all)
+        assert solver.last_info.path == ("lattice-direct" if method == "auto" else "ell-amgpcg") or \
             (method == "ell" and solver.last_info.path == "ell-pcg")      # tiny meshes: no coarse level
     loss = torch_loss(kind, u, g.get("data"))
     loss.backward()
@@ -1060,8 +1061,19 @@ def test_assembled_operators_are_bit_identical_to_the_reference_order():
         plan = get_plan(mesh, torch.device("cuda", 0))
         eng = _Engine(plan, 1e-12, 100, 1, "gather")
         for mode, kap in ((K_SCALAR, np.array(1.37)), (K_ELEM, np.exp(0.4 * rng.standard_normal(m)))):
-            vals, Bv, scale, lift, _ = eng.lattice_assemble(torch.from_numpy(kap), mode, 1, 1)
+            # factor=False: kappa folded into the stored values (what partly-Neumann lattices and per-element kappa
+            # use).  On closed lattices scalar kappa is kept FACTORED, K = kappa * K_1 with the unit matrix stored:
+            # bit-identical to the reference only where the assembly is exact (power-of-two meshes), else to 2 ulp.
+            vals, Bv, scale, lift, _ = eng.lattice_assemble(torch.from_numpy(kap), mode, 1, 1, factor=False)
             v = vals[0].cpu().numpy().reshape(-1, n)
+            if mode == K_SCALAR:
+                vf, Bvf, scf, _, _ = eng.lattice_assemble(torch.from_numpy(kap), mode, 1, 1, factor=True)
+                assert Bvf == 1 and float(scf[0]) == float(kap)
+                vu = vf[0].cpu().numpy().reshape(-1, n) * float(kap)
+                free_rows = ~np.zeros(n, bool)
+                denom = np.maximum(np.abs(v), 1e-300)
+                assert np.max(np.abs(vu - v)[np.abs(v) > 0] / denom[np.abs(v) > 0]) < 5e-16
+                del free_rows
             K, _ = orc.assemble_sparse(mesh.nodes.numpy(), mesh.elements.numpy(), kap, np.zeros(n)); K = K.tocsr()
             is_bc = np.zeros(n, bool); is_bc[list(mesh.dirichlet_nodes.keys())] = True
             W = nx + 1; offs = [0, 1, W, W - 1]; tot = diff = 0
@@ -1102,3 +1114,42 @@ def test_per_call_options_do_not_stick_to_the_solver():
     solver._kappa = torch.tensor([1.0, 2.0], dtype=T64)
     solver(f)
     assert solver.tol == tol_scalar == 1e-12
+
+
+@pytest.mark.gpu
+def test_small_lattices_are_solved_directly_and_mid_sizes_use_the_dense_coarse_level():
+    """The reference's own 2D sizes (up to 32 x 32, scalar kappa, unbatched): one dense product with the cached
+    inverse of the unit matrix, no iteration; larger meshes cut their hierarchy at the 33^2 level the same way, for
+    any batch size.  Per-element kappa (no plan-constant matrix) keeps the iterative path."""
+    for N, B, path in ((32, 1, "lattice-direct"), (24, 3, "lattice-direct"), (32, 70, "lattice-direct"),
+                       (64, 1, "lattice-mgpcg"), (128, 5, "lattice-mgpcg"), (256, 64, "lattice-mgpcg")):
+        mesh = FEMesh.rectangle(N, N, bc_value=0.3)
+        nodes, el, bn, bv = arrays(mesh)
+        rng = np.random.default_rng(N + B)
+        f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+        for kap in (np.float64(1.7), rng.uniform(0.5, 2.0, B)):
+            kt = torch.tensor(kap, dtype=T64, requires_grad=True)
+            ft = torch.from_numpy(f).requires_grad_(True)
+            solver = DifferentiableFESolver(mesh, kt)
+            u = solver(ft)
+            assert solver.last_info.path == path, (N, B, solver.last_info)
+            if path == "lattice-direct":
+                assert solver.last_info.iterations == 0 and solver.last_info.max_relres < 1e-13
+            (u ** 2).sum().backward()
+            dk_tot = 0.0
+            for b in (0, B - 1):
+                kb = float(kap) if np.ndim(kap) == 0 else float(kap[b])
+                uo, dko, dfo = orc.solve_with_adjoint(nodes, el, bn, bv, kb, f[b], lambda u_: 2 * u_)
+                assert rel_err(u[b].detach().numpy(), uo) < RTOL_U
+                assert rel_err(ft.grad[b].numpy(), dfo) < RTOL_GRAD
+                if np.ndim(kap):
+                    assert abs(float(kt.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
+            if np.ndim(kap) == 0 and B <= 3:
+                for b in range(B):
+                    kb = float(kap)
+                    dk_tot += orc.solve_with_adjoint(nodes, el, bn, bv, kb, f[b], lambda u_: 2 * u_)[1].sum()
+                assert abs(float(kt.grad) - dk_tot) < RTOL_GRAD * abs(dk_tot)
+    mesh = FEMesh.rectangle(16, 16)
+    s = DifferentiableFESolver(mesh, torch.rand(mesh.n_elements, dtype=T64) + 0.5)
+    s(torch.ones(mesh.n_nodes, dtype=T64))
+    assert s.last_info.path == "lattice-mgpcg"
