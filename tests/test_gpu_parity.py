@@ -1073,7 +1073,9 @@ def test_assembled_operators_are_bit_identical_to_the_reference_order():
                 bc_ = np.zeros(n, bool); bc_[list(mesh.dirichlet_nodes.keys())] = True
                 for k_, off_ in enumerate([0, 1, nx + 1, nx][:v.shape[0]]):       # free rows x free columns only
                     i_ = np.arange(n - off_); ok_ = ~(bc_[i_] | bc_[i_ + off_]) & (v[k_, i_] != 0)
-                    assert np.max(np.abs(vu[k_, i_[ok_]] - v[k_, i_[ok_]]) / np.abs(v[k_, i_[ok_]])) < 2e-15      # a few ulp
+                    # a few ulp of the contributions an entry is summed from (on skewed meshes the quad-diagonal
+                    # entry is a small difference of two of them): measured against the row's diagonal
+                    assert np.max(np.abs(vu[k_, i_[ok_]] - v[k_, i_[ok_]]) / np.abs(v[0, i_[ok_]])) < 2e-15
             K, _ = orc.assemble_sparse(mesh.nodes.numpy(), mesh.elements.numpy(), kap, np.zeros(n)); K = K.tocsr()
             is_bc = np.zeros(n, bool); is_bc[list(mesh.dirichlet_nodes.keys())] = True
             W = nx + 1; offs = [0, 1, W, W - 1]; tot = diff = 0
