@@ -137,7 +137,9 @@ def main():
     def step():
         kappa.grad = None
         # global mean loss; per-sample kappa: no gradient reduction, ONE fused all-reduce of the scalar loss
-        loss, u = driver.step_local(f, B * world, lambda u_: (u_ ** 2).sum(), kappa)
+        # sum_b sum_i u_b[i]^2 as per-sample squared norms: one reduction pass forward, one elementwise pass backward
+        # (the same loss as (u ** 2).sum(), 24 instead of 40 B per node of torch-side traffic)
+        loss, u = driver.step_local(f, B * world, lambda u_: torch.linalg.vector_norm(u_, dim=1).square().sum(), kappa)
         info = solver.last_info
         iters.append((info.iterations, info.adj_iterations, info.max_relres, info.adj_max_relres,
                       info.not_converged))

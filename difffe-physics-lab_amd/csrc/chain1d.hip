@@ -326,13 +326,15 @@ __device__ inline void scan_blocks(Trip* blk, int lane) {
 // One element's scan inputs: F (load at its LEFT node, 0 at a left Dirichlet end), r = 1/k_e and h_e.
 template <bool ADJ, bool REF>
 __device__ inline void chain_elem(const ChainArgs& A, const double* rhs, const double* kap, int a, int q, bool left_d,
-                                  double& F, double& r, double& he) {
+                                  double& F, double& r, double& he, double& kt) {
   const int e = a + q;
   const double xe = A.x[e];
   he = A.x[e + 1] - xe;                                                        // solver.py:84-86
+  kt = 0.0;
   if (REF) {
     F = (q == 0 && left_d) ? 0.0 : node_load<ADJ, true>(A.x, rhs, e, A.n);
-    r = rcp_newton(kap[(long long)e * A.kse] / he);                            // 1 / fl(kappa / h), solver.py:88
+    kt = kap[(long long)e * A.kse] / he;                                       // fl(kappa / h), solver.py:88
+    r = rcp_newton(kt);
   } else {
     const double w = ADJ ? 1.0 : 0.5 * ((e > 0 ? xe - A.x[e - 1] : 0.0) + he); // solver.py:95-96
     F = (q == 0 && left_d) ? 0.0 : rhs[e] * w;
@@ -358,6 +360,9 @@ __global__ __launch_bounds__(NT) void chain_reg_kernel(ChainArgs A) {
   __shared__ Trip blk_a[NB + 1];        // block composites, then their exclusive prefixes; [NB] = total
   __shared__ Trip blk_b[REF ? NB + 1 : 1];   // REF: the same for the second scan
   __shared__ double red[NW];
+  __shared__ double ktl[REF ? NT * EPT : 1];   // REF: the weights k_e = fl(kappa/h) of the segment (the correction needs
+                                               // each one twice more, and its left neighbour's: 16 B of LDS traffic
+                                               // instead of 1.5 IEEE divisions per element)
   Trip* blk = blk_a;
 
   const int s = blockIdx.x;
@@ -381,8 +386,9 @@ __global__ __launch_bounds__(NT) void chain_reg_kernel(ChainArgs A) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int q = (k * NT + t) * VEC + j;
-      double F = 0.0, r = 0.0, he;
-      if (q < L) chain_elem<ADJ, REF>(A, rhs, kap, a, q, left_d, F, r, he);
+      double F = 0.0, r = 0.0, he, kt = 0.0;
+      if (q < L) chain_elem<ADJ, REF>(A, rhs, kap, a, q, left_d, F, r, he, kt);
+      if (REF && q < L) ktl[q] = kt;
       if (KEEP >= 1) Fk[k * VEC + j] = F;
       if (KEEP >= 2) rk[k * VEC + j] = r;
       run.F += F;
@@ -415,10 +421,9 @@ __global__ __launch_bounds__(NT) void chain_reg_kernel(ChainArgs A) {
         const int q = (k * NT + t) * VEC + j;
         double H = 0.0, r = 0.0;
         if (q < L) {
-          const int e = a + q;
-          const double kc = ref_weight(A.x, kap, A.kse, e);
+          const double kc = ktl[q];
           r = KEEP >= 2 ? rk[k * VEC + j] : rcp_newton(kc);
-          if (j == 0 && q > 0) k_prev = ref_weight(A.x, kap, A.kse, e - 1);
+          if (j == 0 && q > 0) k_prev = ktl[q - 1];
           const double v_left = ua + C * p.R - p.T;        // u0 at node a+q (exclusive prefix)
           H = Fk[k * VEC + j];
           p.F += H;
@@ -463,7 +468,8 @@ __global__ __launch_bounds__(NT) void chain_reg_kernel(ChainArgs A) {
           he = A.x[a + q + 1] - A.x[a + q];
           r = REF ? rcp_newton(kap[(long long)(a + q) * A.kse] / he) : he * rcp_newton(kap[(long long)(a + q) * A.kse]);
         } else {
-          chain_elem<ADJ, false>(A, rhs, kap, a, q, left_d, F, r, he);
+          double kt_;
+          chain_elem<ADJ, false>(A, rhs, kap, a, q, left_d, F, r, he, kt_);
         }
         p.F += F;
         p.R += r;
