@@ -404,21 +404,36 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
                  ("dia_strip_kernel<M_RESID,F_RESTRICT> (residual + restriction, residual never stored)", 2.25 * tv * n * Bp),
                  ("dia_strip_kernel<M_JACOBI,F_PROLONG> (prolongation + correction + sweep)", 3.25 * tv * n * Bp),
                  ("dia_strip_kernel<M_JACOBI> (sweep)", 3.0 * tv * n * Bp)]
+        # HBM bytes per launch from the committed PMC passes (NOT measured in this run): profiles/r02_pmc_traffic.json,
+        # keyed by kernel symbol (fp32 V-cycle storage, shared matrix, 1024^2 x 256)
+        pmc_keys = [None, "pcg_update_kernel", "dia_strip_kernel<float, float, double, 2, 0, 3, true, true",
+                    "dia_strip_kernel<float, float, double, 1, 3", "dia_strip_kernel<float, float, double, 2, 1",
+                    "dia_strip_kernel<float, float, double, 2, 0, 3, true, false"]
+        pmc_tab = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+                pmc2 = json.load(fh)
+            if pmc2.get("pass_bytes") == 8 * n * Bp and f32:
+                pmc_tab = pmc2["kernels"]
+        except Exception:
+            pmc_tab = {}
         table = []
-        for (nm, byt), (ms_, n_) in zip(names, kprof):
+        for (nm, byt), (ms_, n_), pk in zip(names, kprof, pmc_keys):
             if n_ > 0:
                 avg = ms_ * 1e-3 / n_
+                tr = next((v["hbm_bytes_per_launch"] for k_, v in pmc_tab.items() if pk and pk in k_), None)
                 table.append({"kernel": nm, "achieved": round(byt / avg / 1e9, 1), "frac": round(byt / avg / 1e9 / HBM_PEAK_GBS, 4),
                               "bytes_per_launch": byt, "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": int(n_),
-                              "total_ms_timed": round(ms_, 3)})
+                              "total_ms_timed": round(ms_, 3), "traffic": tr})
         table.sort(key=lambda e: -e["total_ms_timed"])
         if table:
             top = table[0]
             other = (other or []) + table[1:]
             if top["kernel"] != kname:      # the fused CG step is no longer the largest: report what is
                 return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": top["frac"], "traffic": None,
-                        "traffic_source": "see profiles/r02_pmc_traffic.json (ratios traffic / algorithmic per kernel)",
+                        "unit": "GB/s", "frac": top["frac"], "traffic": top.get("traffic"),
+                        "traffic_source": "profiles/r02_pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes over this command, same kernel symbol and sizes; NOT measured in this run)",
                         "bytes_per_launch": top["bytes_per_launch"], "avg_launch_ms": top["avg_launch_ms"],
                         "launches_timed": top["launches_timed"],
                         "dominance": "largest in-solver total among the six main kernels of an iteration (HIP events, "
