@@ -1182,3 +1182,43 @@ def test_topology_optimisation_demo_reduces_compliance():
     u.sum().backward()
     uo, dko, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kap, np.ones(mesh.n_nodes), lambda u_: np.ones_like(u_))
     assert rel_err(u.detach().numpy(), uo) < RTOL_U and rel_err(kt.grad.numpy(), dko) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+def test_chain_many_short_segments_and_batches_beyond_the_grid_limit():
+    """(i) A 20 000-element chain cut by 100 interior Dirichlet nodes: every segment fits the register kernel, so no
+    staging buffer is allocated (it used to be sized by n - 1 per segment: ~3 TB at B = 1024).  (ii) 70 000
+    right-hand sides on a tiny chain: beyond the 32 768 of one grid dimension, the batch continues in grid.z."""
+    N = 20_000
+    rng = np.random.default_rng(9)
+    bc = {0: 0.1, N: -0.3}
+    for k in rng.choice(np.arange(1, N), 100, replace=False):
+        bc[int(k)] = float(rng.uniform(-1, 1))
+    mesh = FEMesh(nodes=FEMesh.line(N).nodes, elements=FEMesh.line(N).elements, dirichlet_nodes=bc)
+    plan = get_plan(mesh, torch.device("cuda", 0))
+    assert plan.max_seg_len <= 10240 and plan.n_seg == 101
+    assert _hip.lib().diffhe_chain1d_stage_doubles(mesh.n_nodes, 1024, plan.max_seg_len, 1) == 0
+    nodes, el, bn, bv = arrays(mesh)
+    B = 6
+    f = 1 + 0.5 * rng.standard_normal((B, mesh.n_nodes))
+    kt = torch.tensor(1.4, dtype=T64, requires_grad=True)
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    u = DifferentiableFESolver(mesh, kt)(ft)
+    (u ** 2).sum().backward()
+    dk = 0.0
+    for b in range(B):
+        uo, dko, dfo = orc.chain_solve_longdouble(nodes, bn, bv, 1.4, f[b], lambda u_: 2 * u_, reference_rounding=True)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(ft.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
+        dk += dko.sum()
+    assert abs(float(kt.grad) - dk) < RTOL_GRAD * abs(dk)
+    # (ii)
+    mesh = FEMesh.line(6)
+    B = 70_000
+    f = torch.rand(B, 7, dtype=T64, device="cuda") + 0.5
+    kap = torch.rand(B, dtype=T64, device="cuda") + 0.5
+    u = DifferentiableFESolver(mesh, kap)(f)
+    nodes, el, bn, bv = arrays(mesh)
+    for b in (0, 32_767, 32_768, 65_535, 65_536, B - 1):
+        uo = orc.solve(nodes, el, bn, bv, float(kap[b]), f[b].cpu().numpy())
+        assert rel_err(u[b].cpu().numpy(), uo) < 1e-13
