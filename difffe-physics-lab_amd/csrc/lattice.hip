@@ -758,14 +758,14 @@ __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, T
 template <typename TV>
 __global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, const double* __restrict__ rs,
                                                         double* __restrict__ x, double* __restrict__ part, int n,
-                                                        int Bp) {
+                                                        int Bp, int add = 0) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double inv = rs ? 1.0 / rs[nm.b] : 1.0;  // the start was computed from the scaled right-hand side
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double v = (double)x0[o] * inv;
+    const double v = (double)x0[o] * inv + (add ? x[o] : 0.0);   // add: x0 is a correction of the caller's iterate
     x[o] = v;
     s += v * v;
   }
@@ -1470,6 +1470,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const int nblk = lgrid(n, Bp).x;
   const bool f32 = (precond_fp32 & 1) != 0;
   const bool use_fmg = (precond_fp32 & 2) != 0 && H.nl > 1;
+  const bool warm = (precond_fp32 & 32) != 0;   // x holds an initial guess (e.g. the previous step of an optimisation)
   H.fmg_coarse_cycles = 1 + ((precond_fp32 >> 2) & 3);
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
@@ -1553,10 +1554,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   }
 
   int nbz = 0, nba = 0;
-  const bool light_init = use_fmg && f32;  // the start overwrites x and r; it reads b through r32
+  const bool light_init = (use_fmg && f32) || warm;  // the start overwrites x and r (cold) / x is the caller's guess (warm)
   LAUNCH(light_init ? 8.0 : 24.0, pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
   SCALAR(S_INIT, partA, nblk);
-  if (f32) LAUNCH(12.0, pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
+  if (f32 && !warm) LAUNCH(12.0, pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
   // Fused loop (fine level runs the strip kernels): per iteration
   //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
   //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
@@ -1619,33 +1620,49 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       nba = op_apply_dot(H, p, Ap, partA, st);
     }
   };
-  if (use_fmg) {  // x0 = FMG(b); r = b - A x0
-    if (f32) {
-      const float* x0 = fmg_start<float>(H, (const float*)r32, st);
-      if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(12.0, pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x, use_floor ? partA : (double*)nullptr, n, Bp);
-    } else {
-      const double* x0 = fmg_start<double>(H, b, st);
-      if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(16.0, pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x, use_floor ? partA : (double*)nullptr, n, Bp);
-    }
-    if (use_floor) SCALAR(S_FLOOR, partA, nblk);
+  // r = b - A x (+ its fp32 copy, + the partials b.x and x.(A x) of the energy bound when asked for)
+  auto residual_pass = [&](bool energy) {
     const StripGeom gr = strip_geom(L0, Bp);
-    if (gr.use && f32) {  // r = b - A x and its fp32 copy in one pass
+    if (gr.use && f32) {  // r and its fp32 copy in one pass
       Extra ex{};
       ex.r32 = r32;
       ex.rscale = S.rs;
-      ex.dot_bx = 1;   // the partial sums of this pass: b.x0 and x0.(A x0), the energy bound of S_ENERGY / S_ENERGY2
-      ex.part2 = partB;
-      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, partA, Bp, gr, st, ex);
+      ex.dot_bx = energy ? 1 : 0;   // partial sums of this pass: b.x0 and x0.(A x0) (S_ENERGY / S_ENERGY2)
+      ex.part2 = energy ? partB : nullptr;
+      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, energy ? partA : (double*)nullptr,
+                                           Bp, gr, st, ex);
       nba = gr.ncb * gr.nrc;
     } else {
-      nba = op_residual<double>(H, 0, b, (const double*)x, r, partA, st, 1, partB);
+      nba = op_residual<double>(H, 0, b, (const double*)x, r, energy ? partA : (double*)nullptr, st, energy ? 1 : 0,
+                                energy ? partB : (double*)nullptr);
       if (f32) LAUNCH(12.0, pcg_cvt_kernel, n, (const double*)r, (const double*)S.rs, r32, n, Bp);
     }
-    SCALAR(S_ENERGY, partA, nba);
-    SCALAR(S_ENERGY2, partB, nba);
-    S.have_energy = 1;
+    if (energy) {
+      SCALAR(S_ENERGY, partA, nba);
+      SCALAR(S_ENERGY2, partB, nba);
+      S.have_energy = 1;
+    }
+  };
+  if (use_fmg) {
+    // cold: x0 = FMG(b).  warm: x0 = x + FMG(b - A x) -- the full-multigrid start applied to the residual equation of
+    // the caller's guess (an optimisation loop's previous solution): the start is then as accurate as the guess is
+    // close, times the ~1e-3 of the full-multigrid step itself.
+    if (warm) residual_pass(false);
+    if (f32) {
+      const float* x0 = fmg_start<float>(H, (const float*)r32, st);
+      if (!x0) return DIFFHE_E_LAUNCH;
+      LAUNCH(warm ? 20.0 : 12.0, pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x,
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0);
+    } else {
+      const double* x0 = fmg_start<double>(H, warm ? (const double*)r : b, st);
+      if (!x0) return DIFFHE_E_LAUNCH;
+      LAUNCH(warm ? 24.0 : 16.0, pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x,
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0);
+    }
+    if (use_floor) SCALAR(S_FLOOR, partA, nblk);
+    residual_pass(true);
+  } else if (warm) {
+    residual_pass(true);
   }
   precondition(1);
   rc = diffhe::check_launch();

@@ -318,6 +318,7 @@ class SolvePlan:
         self.coords = dev(nodes.T)                                   # (dim, n) SoA
         self.elems = dev(elements.T.astype(np.int32))                # (npe, m) SoA
         self.pinned_status = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.warm = {}     # ("u" | "lambda", Bp) -> previous (n, Bp) solution, for DifferentiableFESolver(warm_start=True)
 
         # --- 1D chain fast path ---------------------------------------------------------
         self.is_lattice = False

@@ -259,11 +259,13 @@ class _Engine:
             arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None):
+        """x0: (n, Bp) initial guess (warm start; left untouched) or None for the cold full-multigrid start."""
         p, L = self.p, self.L
         arr = self.lattice_levels(vals, vals32, dense)
         nl = len(arr)
-        x = torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
+        warm = x0 is not None and x0.shape == (p.n, Bp)
+        x = x0.clone() if warm else torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
         work = torch.empty(L.diffhe_lattice_pcg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
         iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
@@ -278,7 +280,8 @@ class _Engine:
                                               min(self.max_iter, 500), len(omegas), mg["n_coarse"], om,
                                               int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
                                               | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
-                                              | ((0 if int(mg.get("floor", 1)) else 1) << 4), _hip.ptr(work),
+                                              | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0),
+                                              _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters),
                                               _hip.ptr(p.pinned_status), _stream(p.device)), "diffhe_lattice_pcg_solve")
         st = p.pinned_status
@@ -319,7 +322,8 @@ class _Engine:
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
         iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
         _hip.check(L.diffhe_ell_amg_pcg_solve(arr, nl, Bv, _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
-                                              min(self.max_iter, 2000), int(opts["n_coarse"]), int(opts["gamma"]),
+                                              min(self.max_iter, int(opts.get("max_iter", 20000))), int(opts["n_coarse"]),
+                                              int(opts["gamma"]),
                                               float(opts["scale"]),
                                               int(opts.get("fp32", 0)) | ((0 if int(opts.get("floor", 1)) else 1) << 4),
                                               _hip.ptr(work),
@@ -461,7 +465,10 @@ def _solve_forward(solver, kappa, f):
                 info.path = "lattice-direct"
                 mg = ctx.mg = dict(mg, fp32=0)        # the direct product runs in fp64
             dense = plan.dense_coarse(didx, vals, bool(mg.get("fp32")))
-        x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense)
+        x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense,
+                                              x0=plan.warm.get(("u", Bp)) if solver.warm_start else None)
+        if solver.warm_start and not bad:
+            plan.warm[("u", Bp)] = x                  # never written again: the next solve starts from a copy
         ctx.dense = dense
         ctx.factored = factored
         info.iterations, info.not_converged = its, bad
@@ -529,7 +536,11 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         vals, x, Bp, Bv, scale = ctx.saved
         rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
         if ctx.path in ("lattice-mgpcg", "lattice-direct"):
-            lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense)
+            ws = ctx.solver.warm_start is True
+            lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense,
+                                                    x0=plan.warm.get(("lambda", Bp)) if ws else None)
+            if ws and not bad:
+                plan.warm[("lambda", Bp)] = lam
             info.adj_err_est = float(eng.last_est[:B].max())
         elif ctx.path == "ell-amgpcg":    # same preconditioner (and the saved per-sample coarse operators) as forward
             lam, its, bad, relres = eng.amg_pcg(ctx.amg_hier, rhs, Bp, Bv, ctx.amg)
@@ -667,7 +678,7 @@ class DifferentiableFESolver(nn.Module):
 
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
-                 mg: Optional[dict] = None, chain: str = "reference"):
+                 mg: Optional[dict] = None, chain: str = "reference", warm_start=False):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -684,6 +695,17 @@ class DifferentiableFESolver(nn.Module):
         # diagonal costs 4e-10 in u at 10^4 elements); "exact" is the plain scan, 1e-15 from the exact solution of the
         # unrounded system and ~1.5x faster
         self.chain = chain
+        # warm_start (lattice path): the forward and the adjoint solve start from the previous solution on this mesh
+        # and batch size (kept on the mesh's plan, so a loop that builds a new solver per step -- the reference's
+        # pattern -- still benefits), corrected by one full-multigrid pass on its residual.  For optimisation loops
+        # whose kappa moves a little per step; results meet the same stopping rule, only the iteration count changes.
+        # Costs two (n, B) fp64 vectors of device memory per mesh; `plan.warm.clear()` drops them.
+        # "forward": only the forward solve (an adjoint right-hand side that changes direction from step to step, as
+        # the data misfit of an inverse problem does near its minimum, makes a poor guess: config 5 took 3.6 + 6.3
+        # iterations warm against 5 + 5 cold, 3.6 + 5 with "forward").
+        if warm_start not in (False, True, "forward"):
+            raise ValueError(f"Unknown warm_start: {warm_start!r}")
+        self.warm_start = warm_start
         # "ell": general path (aggregation-AMG PCG) even on lattice meshes; "ell-jacobi": general path
         # with the plain Jacobi preconditioner
         self.method = method
@@ -693,7 +715,13 @@ class DifferentiableFESolver(nn.Module):
         # +13 % on benign fields, but OFF by default -- this cycle is a much weaker preconditioner than the geometric one
         # (50-250 iterations), and on high-contrast fields (kappa spanning 1e5) the fp32 roundings inside it stall or
         # break the CG long before 1e-14 (randomised sweep: 2000 iterations, diverging samples; fp64 cycle: 123)
-        self.amg = dict(n_coarse=16, gamma=1, scale=1.8, fp32=0)
+        # max_iter: this cycle's iteration counts grow with coefficient contrast and element anisotropy (78 on a benign
+        # 84k-node mesh, 4467 on an 86k-node one with an iid e^-4..e^4 field per sample and 6:1 elements, randomised sweep
+        # seed 802 case 6) but the CG keeps converging; a cap of 2000 left that case at 2e-9.
+        self.amg = dict(n_coarse=16, gamma=1, scale=1.8, fp32=0, max_iter=20000)
+        for item in filter(None, os.environ.get("DIFFHE_AMG", "").split(",")):  # e.g. "scale=1.0,gamma=2,max_iter=20000"
+            key, val = item.split("=")
+            self.amg[key] = float(val) if key == "scale" else int(val)
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)

@@ -11,7 +11,9 @@ the same operator).  Update: optimality criteria with a density filter (3 x 3 me
 volume multiplier.  Several designs (different volume fractions) are optimised AT ONCE as one batch:
 kappa has shape (B, n_elements).
 
-    python examples/topology_optimisation.py [N] [iterations]
+    python examples/topology_optimisation.py [N] [iterations] [warm]
+
+`warm`: every solve starts from the previous design's solution (`warm_start=True`).
 """
 import os
 import sys
@@ -38,20 +40,21 @@ def sink_mesh(N):
     return mesh
 
 
-def optimise(N=96, iters=40, volumes=(0.3, 0.4, 0.5), p=3.0, k_min=1e-3, device="cuda", verbose=True):
+def optimise(N=96, iters=40, volumes=(0.3, 0.4, 0.5), p=3.0, k_min=1e-3, device="cuda", verbose=True, warm_start=False):
     mesh = sink_mesh(N)
     B = len(volumes)
     vol = torch.tensor(volumes, dtype=T64, device=device).view(B, 1, 1)
     rho = vol.expand(B, N, N).clone()                      # uniform start at the volume fraction
     f = torch.ones(B, mesh.n_nodes, dtype=T64, device=device)
-    history = []
+    history, n_its = [], 0
     t0 = time.perf_counter()
     for it in range(iters):
         rho_f = F.avg_pool2d(F.pad(rho.unsqueeze(1), (1, 1, 1, 1), mode="replicate"), 3, stride=1).squeeze(1)
         rho_f.requires_grad_(True)
         kq = k_min + (1.0 - k_min) * rho_f ** p                         # (B, N, N) per quad
         kappa = kq.reshape(B, N * N, 1).expand(B, N * N, 2).reshape(B, 2 * N * N)   # both triangles of a quad
-        u = DifferentiableFESolver(mesh, kappa, device=device)(f)
+        solver = DifferentiableFESolver(mesh, kappa, device=device, warm_start=warm_start)
+        u = solver(f)
         C = u.sum(dim=1)                                                # thermal compliance (up to h^2)
         C.sum().backward()
         dC = rho_f.grad                                                 # <= 0: more material never hurts
@@ -68,17 +71,20 @@ def optimise(N=96, iters=40, volumes=(0.3, 0.4, 0.5), p=3.0, k_min=1e-3, device=
             hi = torch.where(too_much, hi, mid)
         rho = cand.detach()
         history.append(C.detach().cpu())
+        n_its += solver.last_info.iterations + solver.last_info.adj_iterations
         if verbose and (it % 10 == 0 or it == iters - 1):
             print(f"  iteration {it:3d}: compliance " + " ".join(f"{float(c):9.3f}" for c in C)
                   + "   volume " + " ".join(f"{float(v):.3f}" for v in rho.mean(dim=(1, 2))))
     dt = time.perf_counter() - t0
+    if verbose:
+        print(f"  mean CG iterations per step (forward + adjoint): {n_its / iters:.1f}")
     return rho, torch.stack(history), dt
 
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    rho, hist, dt = optimise(N, iters)
+    rho, hist, dt = optimise(N, iters, warm_start="warm" in sys.argv[3:])
     print(f"{N}x{N} quads, {hist.shape[1]} designs at once, {iters} iterations in {dt:.1f} s "
           f"({iters * hist.shape[1] / dt:.0f} differentiable solves/s); compliance "
           + ", ".join(f"{float(a):.2f} -> {float(b):.2f}" for a, b in zip(hist[0], hist[-1])))

@@ -249,6 +249,8 @@ typedef struct diffhe_mg_level {
  *            uses the stored p, so the recursion r = b - A x stays exact);
  *            bit 1: start the CG from a full-multigrid iterate x0 instead of 0;
  *            bits 2-3: extra V-cycles per coarse level of that start (0..3);
+ *            bit 5: WARM START -- `x` holds an initial guess on entry (the previous solution of an optimisation
+ *            loop): the solve starts from x + FMG(b - A x) (bit 1 set) or from x itself;
  *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at
  *            |r| <= max(tol |b|, 0.5 u |A_b| |x0_b|), u = 2^-53, |A_b| = 2 scale[b] max_i K_ii: fp64 cannot
  *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the
@@ -261,7 +263,7 @@ typedef struct diffhe_mg_level {
  *            errors are what the parity tolerance is stated in, and the energy norm bounds both far more tightly
  *            than the residual does (1024^2, f = 1: relative residual 6e-9 <-> nodal error 6e-12).  0: off.
  *   err_est  (Bp) out or NULL: the last estimate per sample
- *   b, x     (n, Bp) right-hand side / solution (initial guess 0)
+ *   b, x     (n, Bp) right-hand side / solution (x is read only with flag bit 5; otherwise the start is 0 / FMG(b))
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */
 long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, int n_levels, int Bp);

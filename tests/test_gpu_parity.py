@@ -1222,3 +1222,39 @@ def test_chain_many_short_segments_and_batches_beyond_the_grid_limit():
     for b in (0, 32_767, 32_768, 65_535, 65_536, B - 1):
         uo = orc.solve(nodes, el, bn, bv, float(kap[b]), f[b].cpu().numpy())
         assert rel_err(u[b].cpu().numpy(), uo) < 1e-13
+
+
+@pytest.mark.gpu
+def test_warm_start_meets_the_same_tolerance_in_fewer_iterations():
+    """`warm_start=True` (lattice path): the second solve of a slightly moved per-element kappa field starts from the
+    first one's solution plus a full-multigrid pass on its residual.  Same answer as the cold solve to the parity
+    tolerance, forward and gradient, and no more iterations than it."""
+    N, B = 192, 64
+    DEV = torch.device("cuda", 0)
+    mesh = FEMesh.rectangle(N, N)
+    gen = torch.Generator().manual_seed(77)
+    k0 = torch.exp(0.5 * torch.randn(B, mesh.n_elements, generator=gen, dtype=T64)).to(DEV)
+    k1 = k0 * (1.0 + 0.01 * torch.randn(B, mesh.n_elements, generator=gen, dtype=T64).to(DEV))
+    f = torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64).to(DEV)
+
+    def run(kappa, warm):
+        kk = kappa.clone().requires_grad_(True)
+        s = DifferentiableFESolver(mesh, kk, device=DEV, warm_start=warm)
+        u = s(f)
+        (u ** 2).sum().backward()
+        return u.detach(), kk.grad, s.last_info
+
+    get_plan(mesh, DEV).warm.clear()
+    u_cold, g_cold, i_cold = run(k1, False)
+    run(k0, True)                                    # fills the plan's warm-start vectors
+    u_warm, g_warm, i_warm = run(k1, True)
+    assert i_warm.not_converged == 0
+    assert float((u_warm - u_cold).abs().max() / u_cold.abs().max()) < 1e-10
+    assert float((g_warm - g_cold).abs().max() / g_cold.abs().max()) < 1e-10
+    assert i_warm.iterations <= i_cold.iterations and i_warm.adj_iterations <= i_cold.adj_iterations
+    print(f"warm start: iterations {i_cold.iterations}+{i_cold.adj_iterations} cold -> "
+          f"{i_warm.iterations}+{i_warm.adj_iterations} warm")
+    # a guess from a different batch size is ignored, not misused
+    u2 = DifferentiableFESolver(mesh, k1[:3], device=DEV, warm_start=True)(f[:3])
+    assert float((u2 - u_cold[:3]).abs().max() / u_cold.abs().max()) < 1e-10
+    get_plan(mesh, DEV).warm.clear()

@@ -187,6 +187,10 @@ def test_solver_boundary_quirks():
     bad = FEMesh(nodes=torch.zeros(4, 3, dtype=torch.float64), elements=torch.zeros(1, 4, dtype=torch.long))
     with pytest.raises(NotImplementedError, match="Only 1D and 2D supported"):
         DifferentiableFESolver(bad)(torch.zeros(4))
+    for opt in (dict(warm_start="adjoint"), dict(chain="fast"), dict(method="lu"), dict(assembly="scatter")):
+        with pytest.raises(ValueError, match="Unknown"):
+            DifferentiableFESolver(mesh, **opt)
+    assert DifferentiableFESolver(mesh, warm_start="forward").warm_start == "forward"
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
