@@ -245,6 +245,19 @@ def reference_order_integrals(coords: np.ndarray, elems: np.ndarray):
     return t, np.where(keep, 4.0 * area, 1.0)
 
 
+def _lumped_mass(nodes: np.ndarray, elements: np.ndarray) -> np.ndarray:
+    n = nodes.shape[0]
+    if nodes.shape[1] == 1:
+        size = np.abs(nodes[elements[:, 1], 0] - nodes[elements[:, 0], 0])
+    else:
+        a, b, c = (nodes[elements[:, k]] for k in range(3))
+        size = 0.5 * np.abs((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1]))
+    m = np.zeros(n)
+    for k in range(elements.shape[1]):
+        np.add.at(m, elements[:, k], size / elements.shape[1])
+    return m
+
+
 class LatticeLevel:
     """One level of the multigrid hierarchy of a lattice mesh: geometry, element integrals
     and gather lists on the device.  Level l uses every 2^l-th node of the fine mesh."""
@@ -276,6 +289,8 @@ class LatticeLevel:
         self.store_slot = dev(np.array([0, 1, 2, 3 if self.nd == 4 else -1, -1, -1, -1], dtype=np.int32))
         self._zero_g = None
         self._device = device
+        self._nodes2d = nodes2d
+        self._lumped = None
         # load matrix M in symmetric diagonals (all four: the quad diagonal couples through the centroid rule)
         self.Mvals = None
         if with_load_matrix:
@@ -286,6 +301,13 @@ class LatticeLevel:
                                                   None, _hip.ptr(self.Mvals), None, self.n, self.m, 7, 1,
                                                   _stream(device)), "diffhe_ell_assemble_rows(M, lattice)")
             self._m0 = None
+
+    def lumped_mass(self) -> torch.Tensor:
+        """(n,) lumped mass of this level's own triangulation (coarse levels are re-discretised, like their stiffness)."""
+        if self._lumped is None:
+            m = _lumped_mass(np.ascontiguousarray(self._nodes2d.reshape(self.n, 2)), lattice_elements(self.nx, self.ny))
+            self._lumped = torch.from_numpy(m).to(self._device)
+        return self._lumped
 
     def zero_g(self):
         """Dirichlet values of a coarse level: corrections vanish there."""
@@ -320,6 +342,13 @@ class SolvePlan:
         self.pinned_status = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.warm = {}     # ("u" | "lambda", Bp) -> previous (n, Bp) solution, for DifferentiableFESolver(warm_start=True)
 
+        self._nodes_host = nodes
+        self._lumped_mass = None
+        # the general ELL path is built lazily (`ensure_ell`) for chains and lattices, eagerly for everything else
+        self._elements = elements
+        self._ell_ready = False
+        self.levels = []
+        self.n_bc_interior = 0
         # --- 1D chain fast path ---------------------------------------------------------
         self.is_lattice = False
         self.is_chain = bool(self.dim == 1 and self.n == self.m + 1
@@ -334,10 +363,8 @@ class SolvePlan:
             return
 
         # --- lattice fast path: symmetric diagonals + multigrid hierarchy --------------------
-        self.levels = []
         lat = detect_lattice(elements, self.n) if self.dim == 2 else None
         self.is_lattice = lat is not None
-        self.n_bc_interior = 0
         if self.is_lattice:
             nx, ny = lat
             nodes2d = nodes.reshape(ny + 1, nx + 1, 2)
@@ -355,8 +382,6 @@ class SolvePlan:
 
         # --- general ELL path: built eagerly for general meshes, lazily for lattice meshes (only
         # method="ell" needs it there; the pattern build costs ~20 s of numpy at 1024^2) ------------
-        self._elements = elements
-        self._ell_ready = False
         if not self.is_lattice:
             self.ensure_ell()
 
@@ -386,6 +411,13 @@ class SolvePlan:
             inv = 0.5 * (inv + inv.T)                        # symmetric to the last bit: the cycle stays symmetric
             cache[key] = torch.from_numpy(inv.astype(np.float32) if fp32 else inv).to(self.device).contiguous()
         return idx, cache[key]
+
+    def lumped_mass(self) -> torch.Tensor:
+        """(n,) lumped P1 mass m_i = sum over the elements at node i of |e| / (dim + 1): the row sums of the load
+        matrix of solver.py:95-96 / :143-145.  The reaction term c * u and the heat equation's time derivative use it."""
+        if self._lumped_mass is None:
+            self._lumped_mass = torch.from_numpy(_lumped_mass(self._nodes_host, self._elements)).to(self.device)
+        return self._lumped_mass
 
     def ensure_ell(self):
         """ELL pattern, gather lists, element integrals and the ELL load matrix of the general path."""

@@ -142,6 +142,16 @@ class _Engine:
                                                       p.n, p.m, p.W, Bv, st), "diffhe_ell_assemble_rows_ref")
         return vals, lift
 
+    def add_reaction(self, vals, c, lattice):
+        """A += c M_L on the free rows (M_L = lumped mass, diagonal): the stored main diagonal is slot 0 of both
+        formats.  Lattice: one entry of `vals` per multigrid level, each with its own (re-discretised) lumped mass."""
+        p = self.p
+        for li, v in enumerate(vals):
+            lev = p.levels[li] if lattice else None
+            mass = lev.lumped_mass() if lattice else p.lumped_mass()
+            is_bc = lev.is_bc if lattice else p.is_bc
+            v[0] += (c * torch.where(is_bc.bool(), torch.zeros_like(mass), mass)).unsqueeze(1)
+
     def load_vector(self, f_nm, lift, Bv, Bp, lift_scale=None, lattice=False):
         """F = M f - lift_scale * lift on the free rows, 0 on Dirichlet rows."""
         p = self.p
@@ -359,10 +369,14 @@ class _Engine:
         return dk_e, dk_sum
 
 
-def _solve_forward(solver, kappa, f):
-    """u = K(kappa)^{-1} F(f) with Dirichlet elimination.  Returns (u, state); `state` carries what
-    the explicit adjoint needs (assembled operators, the eliminated solution, layout facts)."""
+def _solve_forward(solver, kappa, f, load=None):
+    """u = (K(kappa) + c M_L)^{-1} (F(f) + load) with Dirichlet elimination (c = solver.reaction, 0 for the reference's
+    problem).  Returns (u, state); `state` carries what the explicit adjoint needs (assembled operators, the
+    eliminated solution, layout facts)."""
     ctx = types.SimpleNamespace()
+    reaction = float(solver.reaction)
+    if load is not None and load.numel() == 0:
+        load = None
     plan: SolvePlan = solver._plan()
     eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
     out_device = f.device
@@ -424,7 +438,23 @@ def _solve_forward(solver, kappa, f):
     ctx.kappa_shape, ctx.kappa_device = kappa.shape, kappa.device
     ctx.kappa_value = kappa.detach().to(plan.device, torch.float64).reshape(-1)[0] if mode == K_SCALAR else None
 
-    if plan.is_chain:
+    load_dev = None
+    if load is not None:      # extra nodal load, added to the assembled F on the free rows
+        load_dev = load.detach().to(plan.device, torch.float64)
+        load_dev = (load_dev.reshape(1, n).expand(B, n) if load_dev.dim() == 1 else load_dev).contiguous()
+        if load_dev.shape != (B, n):
+            raise ValueError(f"load must be (n,) or (B,n) with B={B}, n={n}, got {tuple(load.shape)}")
+    ctx.load_batched = load is not None and load.dim() == 2
+    ctx.reaction = reaction
+    # the scan solver inverts a pure path-graph Laplacian: with a reaction term the chain takes the general path
+    use_chain = plan.is_chain and reaction == 0.0
+    if use_chain and load_dev is not None:
+        # the 1D load map of solver.py:95-96 is diagonal (h/2 from each side): an extra load is a change of forcing
+        f_dev = (f_dev if batched else f_dev.reshape(1, n).expand(B, n)) + load_dev / plan.lumped_mass()
+        batched_dev = True
+    else:
+        batched_dev = batched
+    if use_chain:
         L = eng.L
         kdev = kappa.detach().to(plan.device, torch.float64).contiguous()
         ksb, kse = {K_SCALAR: (0, 0), K_SAMPLE: (1, 0), K_ELEM: (0, 1), K_SAMPLE_ELEM: (m, 1)}[mode]
@@ -435,7 +465,7 @@ def _solve_forward(solver, kappa, f):
         ns = L.diffhe_chain1d_stage_doubles(n, B, plan.max_seg_len, cflags)   # 0: every segment fits the registers
         stage = torch.empty(ns, dtype=torch.float64, device=plan.device) if ns > 0 else None
         _hip.check(L.diffhe_chain1d_solve(_hip.ptr(plan.x), _hip.ptr(kdev), ksb, kse, _hip.ptr(f_dev),
-                                          n if batched else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
+                                          n if batched_dev else 0, _hip.ptr(plan.seg), plan.n_seg, _hip.ptr(plan.g),
                                           _hip.ptr(u), n, n, B, plan.max_seg_len, cflags, _hip.ptr(stage),
                                           _stream(plan.device)), "diffhe_chain1d_solve")
         ctx.chain_flags = cflags
@@ -451,12 +481,17 @@ def _solve_forward(solver, kappa, f):
         # from ~33^2 nodes down are replaced by ONE dense product with the cached inverse of that level's matrix (they
         # cost ~45 launch-bound launches per cycle); a mesh that small as a whole -- the reference's own 2D sizes -- is
         # solved DIRECTLY by that product (level index 0: no iteration at all)
-        factored = closed_ and mode in (K_SCALAR, K_SAMPLE)
+        # a reaction term c M_L does not scale with kappa: K_b + c M_L is assembled per sample (or once, scalar kappa)
+        factored = closed_ and mode in (K_SCALAR, K_SAMPLE) and reaction == 0.0
         didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1)) else None
-        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_,
+        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_ and reaction == 0.0,
                                                                  n_levels=None if didx is None else didx + 1)
+        if reaction:
+            eng.add_reaction(vals, reaction, lattice=True)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
+        if load_dev is not None:
+            rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
         # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
         vals32 = [v.float() for v in vals] if (Bv != 1 and mg.get("fp32")) else None
         dense = None
@@ -483,8 +518,12 @@ def _solve_forward(solver, kappa, f):
         Bp = padded_batch(B)
         kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
         vals, lift = eng.assemble(kdev, kse, ksb, Bv)
+        if reaction:
+            eng.add_reaction([vals], reaction, lattice=False)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp)
+        if load_dev is not None:
+            rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
         ctx.amg_hier = None
         if solver.method != "ell-jacobi":
             plan.ensure_amg()
@@ -509,14 +548,17 @@ def _solve_forward(solver, kappa, f):
     return out.to(out_device), ctx
 
 
-def _solve_backward(ctx, gbar, need_k, need_f):
+def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
     """Explicit adjoint: lambda = K_free^{-1} gbar_free with the saved operators,
-    dL/dkappa = -lambda^T k0 u, dL/df = M^T lambda.  Returns (grad_kappa | None, grad_f | None)."""
+    dL/dkappa = -lambda^T k0 u, dL/df = M^T lambda, dL/dload = lambda.
+    Returns (grad_kappa | None, grad_f | None, grad_load | None)."""
     plan, eng, mode, B = ctx.plan, ctx.eng, ctx.mode, ctx.B
     m, n = plan.m, plan.n
     g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
     info = ctx.solver.last_info
-    if plan.is_chain:
+    grad_load = None
+    if ctx.path.startswith("chain1d"):
+        need_f_user, need_f = need_f, need_f or need_load    # the chain's extra load went in as forcing
         kdev, ksb, kse, u = ctx.saved
         L = eng.L
         df = torch.empty((B, n), dtype=torch.float64, device=plan.device)
@@ -532,6 +574,9 @@ def _solve_backward(ctx, gbar, need_k, need_f):
                    "diffhe_chain1d_adjoint")
         dk_sample = part.sum(dim=1)                      # (B,) tiny host-side glue
         dk_elem = dk_e
+        if need_load:
+            grad_load = df / plan.lumped_mass()
+        need_f = need_f_user
     else:
         vals, x, Bp, Bv, scale = ctx.saved
         rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
@@ -551,7 +596,8 @@ def _solve_backward(ctx, gbar, need_k, need_f):
         info.not_converged += bad
         want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
         dk_nm = dk_sum = None
-        if need_k and ctx.path in ("lattice-mgpcg", "lattice-direct") and mode in (K_SCALAR, K_SAMPLE) and Bv == 1:
+        if need_k and ctx.path in ("lattice-mgpcg", "lattice-direct") and mode in (K_SCALAR, K_SAMPLE) and Bv == 1 \
+                and not ctx.reaction:
             dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
             if dk_sum is not None and mode == K_SCALAR and not ctx.factored:
                 dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
@@ -563,6 +609,8 @@ def _solve_backward(ctx, gbar, need_k, need_f):
             dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
         df = eng.to_sample_major(eng.apply_M(lam, Bp, lattice=ctx.path.startswith("lattice-")), B, Bp, n) \
             if need_f else None
+        if need_load:
+            grad_load = eng.to_sample_major(lam, B, Bp, n)
 
     grad_k = None
     if need_k:
@@ -579,7 +627,9 @@ def _solve_backward(ctx, gbar, need_k, need_f):
     if need_f:
         grad_f = df if ctx.batched_f else df.sum(dim=0)
         grad_f = grad_f.to(ctx.out_device)
-    return grad_k, grad_f
+    if grad_load is not None:
+        grad_load = (grad_load if ctx.load_batched else grad_load.sum(dim=0)).to(ctx.out_device)
+    return grad_k, grad_f, grad_load
 
 
 
@@ -606,11 +656,12 @@ class _StateGuard:
 
 
 @torch.library.custom_op("diffhe::fe_solve", mutates_args=())
-def fe_solve(kappa: torch.Tensor, f: torch.Tensor, handle: int, save: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+def fe_solve(kappa: torch.Tensor, f: torch.Tensor, load: torch.Tensor, handle: int,
+             save: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """(u, token) = solve with the solver registered under `handle`; `token` names the saved
-    adjoint state (0 when `save` is false)."""
+    adjoint state (0 when `save` is false).  `load`: extra nodal load vector, empty for none."""
     solver = _SOLVERS[handle]
-    u, state = _solve_forward(solver, kappa, f)
+    u, state = _solve_forward(solver, kappa, f, load)
     token = 0
     if save:
         token = next(_TOKENS)
@@ -619,7 +670,7 @@ def fe_solve(kappa: torch.Tensor, f: torch.Tensor, handle: int, save: bool) -> T
 
 
 @fe_solve.register_fake
-def _fe_solve_fake(kappa, f, handle, save):
+def _fe_solve_fake(kappa, f, load, handle, save):
     solver = _SOLVERS[handle]
     n, m = solver.mesh.n_nodes, solver.mesh.n_elements
     B_f = f.shape[0] if f.dim() == 2 else None
@@ -630,34 +681,37 @@ def _fe_solve_fake(kappa, f, handle, save):
 
 
 @torch.library.custom_op("diffhe::fe_solve_backward", mutates_args=())
-def fe_solve_backward(gbar: torch.Tensor, token: torch.Tensor, need_k: bool, need_f: bool,
-                      kappa_like: torch.Tensor, f_like: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(dL/dkappa, dL/df) for the forward call named by `token`; unused gradients come back empty."""
+def fe_solve_backward(gbar: torch.Tensor, token: torch.Tensor, need_k: bool, need_f: bool, need_load: bool,
+                      kappa_like: torch.Tensor, f_like: torch.Tensor,
+                      load_like: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dL/dkappa, dL/df, dL/dload) for the forward call named by `token`; unused gradients come back empty."""
     state = _STATES.get(int(token))
     if state is None:
         raise RuntimeError("diffhe: adjoint state of this solve is gone (its autograd graph was freed)")
-    gk, gf = _solve_backward(state, gbar, need_k, need_f)
-    return (gk if gk is not None else kappa_like.new_empty(0), gf if gf is not None else f_like.new_empty(0))
+    gk, gf, gl = _solve_backward(state, gbar, need_k, need_f, need_load)
+    return (gk if gk is not None else kappa_like.new_empty(0), gf if gf is not None else f_like.new_empty(0),
+            gl.to(load_like.dtype) if gl is not None else load_like.new_empty(0))
 
 
 @fe_solve_backward.register_fake
-def _fe_solve_backward_fake(gbar, token, need_k, need_f, kappa_like, f_like):
+def _fe_solve_backward_fake(gbar, token, need_k, need_f, need_load, kappa_like, f_like, load_like):
     return (torch.empty_like(kappa_like) if need_k else kappa_like.new_empty(0),
-            torch.empty_like(f_like) if need_f else f_like.new_empty(0))
+            torch.empty_like(f_like) if need_f else f_like.new_empty(0),
+            torch.empty_like(load_like) if need_load else load_like.new_empty(0))
 
 
 def _fe_setup_context(ctx, inputs, output):
-    kappa, f, _, _ = inputs
-    ctx.save_for_backward(output[1], kappa, f)
+    kappa, f, load, _, _ = inputs
+    ctx.save_for_backward(output[1], kappa, f, load)
     if not isinstance(output[1], torch._subclasses.FakeTensor):
         ctx.state_guard = _StateGuard(int(output[1]))       # frees the adjoint state together with the graph
 
 
 def _fe_backward(ctx, grad_u, _grad_token):
-    token, kappa, f = ctx.saved_tensors
-    need_k, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-    gk, gf = torch.ops.diffhe.fe_solve_backward(grad_u, token, need_k, need_f, kappa, f)
-    return (gk if need_k else None), (gf if need_f else None), None, None
+    token, kappa, f, load = ctx.saved_tensors
+    need_k, need_f, need_load = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    gk, gf, gl = torch.ops.diffhe.fe_solve_backward(grad_u, token, need_k, need_f, need_load, kappa, f, load)
+    return (gk if need_k else None), (gf if need_f else None), (gl if need_load else None), None, None
 
 
 torch.library.register_autograd("diffhe::fe_solve", _fe_backward, setup_context=_fe_setup_context)
@@ -678,7 +732,7 @@ class DifferentiableFESolver(nn.Module):
 
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
-                 mg: Optional[dict] = None, chain: str = "reference", warm_start=False):
+                 mg: Optional[dict] = None, chain: str = "reference", warm_start=False, reaction: float = 0.0):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -695,6 +749,13 @@ class DifferentiableFESolver(nn.Module):
         # diagonal costs 4e-10 in u at 10^4 elements); "exact" is the plain scan, 1e-15 from the exact solution of the
         # unrounded system and ~1.5x faster
         self.chain = chain
+        # reaction >= 0 (ours; the reference solves pure diffusion): the problem becomes -div(kappa grad u) + c u = f,
+        # discretised as (K + c M_L) u = F with the LUMPED mass M_L = row sums of the reference's load matrix
+        # (solver.py:95-96, :143-145).  One backward-Euler step of the heat equation is this with c = 1 / dt
+        # (diffhe/heat.py).  A fixed number, not differentiated.
+        if not (float(reaction) >= 0.0):
+            raise ValueError(f"reaction must be >= 0, got {reaction!r}")
+        self.reaction = float(reaction)
         # warm_start (lattice path): the forward and the adjoint solve start from the previous solution on this mesh
         # and batch size (kept on the mesh's plan, so a loop that builds a new solver per step -- the reference's
         # pattern -- still benefits), corrected by one full-multigrid pass on its residual.  For optimisation loops
@@ -756,9 +817,11 @@ class DifferentiableFESolver(nn.Module):
     def _plan(self) -> SolvePlan:
         return get_plan(self.mesh, _resolve_device(self._device))
 
-    def forward(self, f: torch.Tensor) -> torch.Tensor:
+    def forward(self, f: torch.Tensor, load: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Solve for nodal u.  f: (n,), (n,1) or (B,n); returns float64 (n,) or (B,n)
-        on f's device (reference solver.py:49-67 returns CPU float64)."""
+        on f's device (reference solver.py:49-67 returns CPU float64).
+        load (ours): (n,) or (B,n) nodal load added to the assembled load vector F on the free rows (differentiable) --
+        the M_L u_prev / dt term of a time step, point sources, a Neumann flux integrated by the caller."""
         if self.mesh.dim not in (1, 2):
             raise NotImplementedError("Only 1D and 2D supported")       # reference solver.py:67
         n = self.mesh.n_nodes
@@ -770,8 +833,16 @@ class DifferentiableFESolver(nn.Module):
         elif f64.dim() == 1 and f64.shape[0] != n:
             raise ValueError(f"f must have {n} nodal values, got {f64.shape[0]}")
         _SOLVERS[id(self)] = self
-        save = torch.is_grad_enabled() and (self._kappa.requires_grad or f64.requires_grad)
-        u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, id(self), save)
+        if load is None:
+            load64 = f64.new_empty(0)
+        else:
+            load64 = load.to(torch.float64)
+            if load64.shape[-1] != n or load64.dim() not in (1, 2):
+                raise ValueError(f"load must be (n,) or (B,n) with n={n}, got {tuple(load.shape)}")
+            if load64.dim() == 2 and f64.dim() == 1:
+                f64 = f64.reshape(1, n).expand(load64.shape[0], n)
+        save = torch.is_grad_enabled() and (self._kappa.requires_grad or f64.requires_grad or load64.requires_grad)
+        u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, load64, id(self), save)
         return u
 
     # reference-private names kept as aliases; both run the HIP path

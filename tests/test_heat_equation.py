@@ -1,0 +1,203 @@
+"""Reaction-diffusion solves (`DifferentiableFESolver(..., reaction=c)`, the `load=` input) and the heat-equation
+time stepping of `diffhe.heat.HeatEquation` on the HIP path, against `oracle/heat_oracle.py` (whose own pins are
+closed forms: tests/test_oracle_golden.py) and against exact decay factors of discrete eigenmodes at full size.
+The reference has neither (its README roadmap names the heat equation): SURVEY 8(f) rank 4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from diffhe import FEMesh, DifferentiableFESolver
+from diffhe.heat import HeatEquation
+from oracle import heat_oracle as ho
+from _util import rel_err, RTOL_U, RTOL_GRAD
+
+T64 = torch.float64
+
+
+def _arrays(mesh):
+    bn = np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64)
+    bv = np.fromiter(mesh.dirichlet_nodes.values(), dtype=np.float64)
+    return mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv
+
+
+def _shuffled(mesh, seed):
+    """The same triangulation with nodes and elements in random order: no lattice structure left to detect."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(mesh.n_nodes)
+    nodes = np.empty_like(mesh.nodes.numpy())
+    nodes[perm] = mesh.nodes.numpy()
+    el = perm[mesh.elements.numpy()][rng.permutation(mesh.n_elements)]
+    return FEMesh(torch.from_numpy(nodes), torch.from_numpy(el), {int(perm[k]): v for k, v in mesh.dirichlet_nodes.items()})
+
+
+def _meshes():
+    return {
+        "line": FEMesh.line(60, -1.0, 2.0, 0.4, -0.7),                                   # chain -> general path
+        "line_neumann": FEMesh.line(33, 0.0, 1.0, None, 0.5),
+        "rect": FEMesh.rectangle(24, 20, (0.0, 2.0), (0.0, 1.0), 0.3),                    # lattice path
+        "unstructured": _shuffled(FEMesh.rectangle(17, 13, (0.0, 1.0), (0.0, 1.0), -0.2), 5),
+    }
+
+
+def test_heat_equation_argument_checks():
+    mesh = FEMesh.line(5)
+    with pytest.raises(ValueError, match="dt must be > 0"):
+        HeatEquation(mesh, 1.0, dt=0.0)
+    with pytest.raises(ValueError, match="theta"):
+        HeatEquation(mesh, 1.0, dt=0.1, theta=0.7)
+    with pytest.raises(ValueError, match="reaction must be >= 0"):
+        DifferentiableFESolver(mesh, 1.0, reaction=-1.0)
+    h = HeatEquation(mesh, 2.0, dt=0.25, theta=0.5)
+    assert h.solver.reaction == 8.0 and float(h.kappa) == 2.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["line", "line_neumann", "rect", "unstructured"])
+@pytest.mark.parametrize("kmode", ["scalar", "sample", "elem", "sample_elem"])
+def test_reaction_diffusion_matches_oracle(kind, kmode):
+    """(K + c M_L) u = M f + load: u, dL/dkappa, dL/df and dL/dload of L = sum u^2 against the CPU oracle, for every
+    kappa layout, on the chain (general path: the scan solver has no reaction term), lattice and unstructured meshes."""
+    mesh = _meshes()[kind]
+    nodes, el, bn, bv = _arrays(mesh)
+    n, m, B, c = mesh.n_nodes, mesh.n_elements, 3, 7.3
+    rng = np.random.default_rng(11)
+    kap = {"scalar": np.array(1.3), "sample": rng.uniform(0.5, 2.0, B), "elem": np.exp(0.4 * rng.standard_normal(m)),
+           "sample_elem": np.exp(0.4 * rng.standard_normal((B, m)))}[kmode]
+    f = 1.0 + 0.5 * rng.standard_normal((B, n))
+    load = 0.1 * rng.standard_normal((B, n)) * ho.lumped_mass(nodes, el)
+    kt = torch.from_numpy(np.asarray(kap)).cuda().requires_grad_(True)
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    lt = torch.from_numpy(load).cuda().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt, reaction=c)
+    u = solver(ft, load=lt)
+    (u ** 2).sum().backward()
+    assert not solver.last_info.path.startswith("chain1d") and solver.last_info.not_converged == 0
+    dk_ref = np.zeros_like(np.atleast_1d(kap), dtype=np.float64)
+    for b in range(B):
+        kb = kap if kmode in ("scalar", "elem") else kap[b]
+        rd = ho.ReactionDiffusion(nodes, el, bn, bv, kb, c)
+        uo = rd.solve(f[b], load=load[b])
+        lam, dko, dfo, dlo = rd.adjoint(uo, 2.0 * uo)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(ft.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
+        assert rel_err(lt.grad[b].cpu().numpy(), dlo) < RTOL_GRAD
+        if kmode == "scalar":
+            dk_ref += dko.sum()
+        elif kmode == "sample":
+            dk_ref[b] = dko.sum()
+        elif kmode == "elem":
+            dk_ref += dko
+        else:
+            dk_ref[b] = dko
+    assert rel_err(kt.grad.cpu().numpy().reshape(dk_ref.shape), dk_ref) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["line", "rect"])
+def test_extra_load_without_reaction(kind):
+    """reaction = 0 keeps the reference's operator (1D: the scan solver, the load folded into the forcing through the
+    diagonal 1D load map); `load` shifts the right-hand side, unbatched f and batched load broadcast."""
+    mesh = _meshes()[kind]
+    nodes, el, bn, bv = _arrays(mesh)
+    n, B = mesh.n_nodes, 4
+    rng = np.random.default_rng(2)
+    f = 1.0 + 0.5 * rng.standard_normal(n)
+    load = 0.05 * rng.standard_normal((B, n))
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    lt = torch.from_numpy(load).cuda().requires_grad_(True)
+    kt = torch.tensor(1.4, dtype=T64, device="cuda", requires_grad=True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(ft, load=lt)
+    assert u.shape == (B, n) and solver.last_info.path.startswith("chain1d" if kind == "line" else "lattice")
+    (u ** 2).sum().backward()
+    rd = ho.ReactionDiffusion(nodes, el, bn, bv, 1.4, 0.0)
+    df_ref, dk_ref = np.zeros(n), 0.0
+    for b in range(B):
+        uo = rd.solve(f, load=load[b])
+        lam, dko, dfo, dlo = rd.adjoint(uo, 2.0 * uo)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(lt.grad[b].cpu().numpy(), dlo) < RTOL_GRAD
+        df_ref += dfo
+        dk_ref += dko.sum()
+    assert rel_err(ft.grad.cpu().numpy(), df_ref) < RTOL_GRAD
+    assert abs(float(kt.grad) - dk_ref) < RTOL_GRAD * abs(dk_ref)
+    # a 1-D load is shared by the batch and its gradient is summed over it
+    l1 = torch.from_numpy(load[0]).cuda().requires_grad_(True)
+    kb = torch.tensor([1.0, 1.4], dtype=T64, device="cuda")
+    u2 = DifferentiableFESolver(mesh, kb)(torch.from_numpy(f).cuda(), load=l1)
+    (u2 ** 2).sum().backward()
+    assert rel_err(u2[1].detach().cpu().numpy(), rd.solve(f, load=load[0])) < RTOL_U
+    g = sum(ho.ReactionDiffusion(nodes, el, bn, bv, k, 0.0).adjoint(u2[i].detach().cpu().numpy(),
+                                                                     2.0 * u2[i].detach().cpu().numpy())[3]
+            for i, k in enumerate((1.0, 1.4)))
+    assert rel_err(l1.grad.cpu().numpy(), g) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_heat_march_matches_oracle_with_gradients(theta):
+    """4 steps with a time-dependent forcing, non-zero Dirichlet value, one per-element kappa field per sample:
+    the whole history, dL/dkappa_e and dL/du0 of L = sum u(T)^2 against the oracle's forward march and its
+    backward-in-time adjoint (autograd here = one adjoint HIP solve per step, in reverse)."""
+    mesh = FEMesh.rectangle(16, 12, (0.0, 1.5), (0.0, 1.0), 0.3)
+    nodes, el, bn, bv = _arrays(mesh)
+    n, m, B, dt, steps = mesh.n_nodes, mesh.n_elements, 3, 0.02, 4
+    rng = np.random.default_rng(8)
+    kap = np.exp(0.3 * rng.standard_normal((B, m)))
+    u0 = rng.standard_normal((B, n))
+    f0 = 1.0 + rng.standard_normal(n)
+    kt = torch.from_numpy(kap).cuda().requires_grad_(True)
+    ut = torch.from_numpy(u0).cuda().requires_grad_(True)
+    f_dev = torch.from_numpy(f0).cuda()
+    heat = HeatEquation(mesh, kt, dt=dt, theta=theta)
+    hist = heat(ut, steps, f=lambda t: math.cos(3.0 * t) * f_dev, return_all=True)
+    assert hist.shape == (steps + 1, B, n)
+    (hist[-1] ** 2).sum().backward()
+    for b in range(B):
+        ho_hist, dk, du0 = ho.heat_march(nodes, el, bn, bv, kap[b], u0[b], dt, steps, f=lambda t: math.cos(3.0 * t) * f0,
+                                         theta=theta, gbar_fn=lambda u: 2.0 * u)
+        assert rel_err(hist[:, b].detach().cpu().numpy(), ho_hist) < RTOL_U
+        assert rel_err(kt.grad[b].cpu().numpy(), dk) < RTOL_GRAD
+        assert rel_err(ut.grad[b].cpu().numpy(), du0) < RTOL_GRAD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_heat_eigenmode_decay_at_full_size(theta):
+    """Size-independent property at the bench mesh size (1024^2, strip kernels, 64 kappa samples marching together):
+    the discrete eigenmode sin(pi x) sin(pi y) decays by EXACTLY 1 / (1 + z_b) (backward Euler) or
+    (1 - z_b / 2) / (1 + z_b / 2) (Crank-Nicolson) per step, z_b = dt kappa_b (4 - 4 cos(pi h)) / h^2."""
+    N, B, dt, steps = 1024, 64, 2e-3, 3
+    mesh = FEMesh.rectangle(N, N)
+    h = 1.0 / N
+    mu = (4.0 - 4.0 * math.cos(math.pi * h)) / h ** 2
+    gen = torch.Generator().manual_seed(31)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).cuda()
+    xy = mesh.nodes.cuda()
+    mode = torch.sin(math.pi * xy[:, 0]) * torch.sin(math.pi * xy[:, 1])
+    mode[torch.as_tensor(list(mesh.dirichlet_nodes.keys()), device="cuda")] = 0.0
+    heat = HeatEquation(mesh, kappa, dt=dt, theta=theta)
+    u = heat(mode.expand(B, -1), steps)
+    z = dt * kappa * mu
+    fac = 1.0 / (1.0 + z) if theta == 1.0 else (1.0 - z / 2) / (1.0 + z / 2)
+    err = (u - (fac ** steps).unsqueeze(1) * mode).abs().max() / mode.abs().max()
+    assert heat.solver.last_info.path == "lattice-mgpcg" and heat.solver.last_info.not_converged == 0
+    print(f"heat eigenmode decay 1024^2 x {B}, theta={theta}: max error {float(err):.2e}, "
+          f"{heat.solver.last_info.iterations} iterations in the last step")
+    assert float(err) < RTOL_U
+
+
+@pytest.mark.gpu
+def test_heat_equation_example_recovers_conductivities():
+    """examples/heat_equation.py: kappa of every sample from its final temperature field, Adam through the
+    discrete adjoint heat equation."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "heat_equation.py")
+    spec = importlib.util.spec_from_file_location("heat_equation_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    err, _, _ = mod.main(N=64, B=8, steps=5, n_opt=80, verbose=False)
+    assert err < 0.1          # from 0.9 at the start (kappa_0 = 1, kappa_true in [0.5, 2])

@@ -272,15 +272,17 @@ def test_custom_ops_are_registered_with_shape_inference():
     S._SOLVERS[id(s)] = s
     with FakeTensorMode():
         k1, f1 = torch.empty((), dtype=torch.float64), torch.empty(25, dtype=torch.float64)
-        u, tok = torch.ops.diffhe.fe_solve(k1, f1, id(s), False)
+        u, tok = torch.ops.diffhe.fe_solve(k1, f1, f1.new_empty(0), id(s), False)
         assert u.shape == (25,) and u.dtype == torch.float64 and tok.shape == ()
         kb, fb = torch.empty(6, dtype=torch.float64), torch.empty(6, 25, dtype=torch.float64)
-        u, _ = torch.ops.diffhe.fe_solve(kb, fb, id(s), False)
+        u, _ = torch.ops.diffhe.fe_solve(kb, fb, fb.new_empty(0), id(s), False)
         assert u.shape == (6, 25)
-        u, _ = torch.ops.diffhe.fe_solve(kb, f1, id(s), False)          # kappa batch, shared f
+        u, _ = torch.ops.diffhe.fe_solve(kb, f1, f1.new_empty(0), id(s), False)          # kappa batch, shared f
         assert u.shape == (6, 25)
-        gk, gf = torch.ops.diffhe.fe_solve_backward(u, tok, True, False, kb, f1)
-        assert gk.shape == (6,) and gf.numel() == 0
+        gk, gf, gl = torch.ops.diffhe.fe_solve_backward(u, tok, True, False, False, kb, f1, f1.new_empty(0))
+        assert gk.shape == (6,) and gf.numel() == 0 and gl.numel() == 0
+        gk, gf, gl = torch.ops.diffhe.fe_solve_backward(u, tok, False, True, True, kb, f1, fb)   # load (B, n)
+        assert gk.numel() == 0 and gf.shape == (25,) and gl.shape == (6, 25)
 
 
 def test_coarsening_step_rules():

@@ -262,3 +262,63 @@ def test_longdouble_chain_oracle_with_reference_rounding():
                                                reference_rounding=True)
         assert rel_err(u, h["u"]) < 1e-11 and rel_err(df, h["df"]) < 1e-11
         assert abs(dk.sum() - float(h["dkappa"])) < 1e-11 * abs(float(h["dkappa"]))
+
+
+# ---- reaction-diffusion / heat equation oracle (oracle/heat_oracle.py): no reference counterpart, closed forms instead ----
+def test_heat_oracle_reaction_diffusion_discrete_eigenmode():
+    """sin(pi x_j) is an eigenvector of the uniform 1D P1 stiffness (eigenvalue mu h, mu = (2 - 2 cos(pi h)) / h^2);
+    lumped mass and the 1D load map are both h on interior rows: f = (kappa mu + c) u reproduces u to rounding."""
+    from oracle import heat_oracle as ho
+    N, kappa, c = 40, 1.7, 23.0
+    nodes, el, bn, bv = orc.mesh_line(N)
+    h = 1.0 / N
+    mu = (2.0 - 2.0 * math.cos(math.pi * h)) / h ** 2
+    u_exact = np.sin(math.pi * nodes[:, 0])
+    u_exact[[0, -1]] = 0.0
+    rd = ho.ReactionDiffusion(nodes, el, bn, bv, kappa, c)
+    assert np.allclose(rd.mass[1:-1], h) and np.allclose(rd.mass[[0, -1]], h / 2)
+    assert rel_err(rd.solve((kappa * mu + c) * u_exact), u_exact) < 1e-13
+    assert rel_err(ho.ReactionDiffusion(nodes, el, bn, bv, kappa, 0.0).solve(kappa * mu * u_exact), u_exact) < 1e-13
+
+
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_heat_oracle_eigenmode_decay(theta):
+    """f = 0, u0 = discrete eigenmode: backward Euler multiplies it by 1 / (1 + dt kappa mu) per step,
+    Crank-Nicolson by (1 - dt kappa mu / 2) / (1 + dt kappa mu / 2).  1D and the 2D right-triangle lattice
+    (5-point stencil, lumped mass h^2: mu = (4 - 4 cos(pi h)) / h^2)."""
+    from oracle import heat_oracle as ho
+    kappa, dt, steps = 0.8, 3e-3, 7
+    for dim in (1, 2):
+        N = 24 if dim == 1 else 12
+        nodes, el, bn, bv = orc.mesh_line(N) if dim == 1 else orc.mesh_rectangle(N, N)
+        hh = 1.0 / N
+        mu = dim * (2.0 - 2.0 * math.cos(math.pi * hh)) / hh ** 2
+        u0 = np.prod(np.sin(math.pi * nodes), axis=1)
+        u0[bn] = 0.0
+        hist = ho.heat_march(nodes, el, bn, bv, kappa, u0, dt, steps, theta=theta)
+        z = dt * kappa * mu
+        fac = 1.0 / (1.0 + z) if theta == 1.0 else (1.0 - z / 2) / (1.0 + z / 2)
+        for k in range(steps + 1):
+            assert rel_err(hist[k], fac ** k * u0) < 1e-12
+
+
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+def test_heat_oracle_adjoint_matches_finite_differences(theta):
+    """The backward-in-time adjoint of heat_march against central differences of L = sum u(T)^2 in a per-element
+    kappa and in the initial state (non-zero Dirichlet value, a forcing, 2D)."""
+    from oracle import heat_oracle as ho
+    nodes, el, bn, bv = orc.mesh_rectangle(5, 4, (0.0, 1.5), (0.0, 1.0), 0.3)
+    rng = np.random.default_rng(3)
+    kap = np.exp(0.3 * rng.standard_normal(len(el)))
+    u0 = rng.standard_normal(len(nodes))
+    f = 1.0 + rng.standard_normal(len(nodes))
+    L = lambda k_, u_: float(np.sum(ho.heat_march(nodes, el, bn, bv, k_, u_, 0.05, 4, f=f, theta=theta)[-1] ** 2))  # noqa: E731
+    _, dk, du0 = ho.heat_march(nodes, el, bn, bv, kap, u0, 0.05, 4, f=f, theta=theta, gbar_fn=lambda u: 2 * u)
+    free = orc.free_nodes(len(nodes), bn)
+    for e in (0, 7, len(el) - 1):
+        d = np.zeros(len(el)); d[e] = 1e-6
+        assert abs((L(kap + d, u0) - L(kap - d, u0)) / 2e-6 - dk[e]) < 1e-7 * max(1.0, abs(dk[e]))
+    for i in (int(free[0]), int(free[len(free) // 2])):
+        d = np.zeros(len(nodes)); d[i] = 1e-6
+        assert abs((L(kap, u0 + d) - L(kap, u0 - d)) / 2e-6 - du0[i]) < 1e-7 * max(1.0, abs(du0[i]))
+    assert np.all(du0[bn] == 0.0)
