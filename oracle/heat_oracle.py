@@ -69,6 +69,11 @@ class ReactionDiffusion:
         df = _load_transpose(self.nodes, self.elements, lam)
         return lam, dkappa, df, lam.copy()
 
+    def gradient_scale(self, u, lam):
+        """sum_{p,q} |lambda_p| |k0_e[p,q]| |u_q| per element: the magnitude of the terms dL/dkappa_e is made of.  Where
+        u is nearly constant over an element they cancel, and fp64 defines the gradient only to u * that magnitude."""
+        return np.einsum("ep,epq,eq->e", np.abs(lam[self.elements]), np.abs(self.k0), np.abs(u[self.elements]))
+
 
 def _load_transpose(nodes, elements, lam):
     """M^T lambda for the load map of solver.py:95-96 (1D) / :143-145 (2D) (as p1_oracle.solve_with_adjoint)."""
@@ -85,11 +90,13 @@ def _load_transpose(nodes, elements, lam):
     return df
 
 
-def heat_march(nodes, elements, bc_nodes, bc_vals, kappa, u0, dt, n_steps, f=None, theta=1.0, gbar_fn=None):
+def heat_march(nodes, elements, bc_nodes, bc_vals, kappa, u0, dt, n_steps, f=None, theta=1.0, gbar_fn=None,
+               with_scale=False):
     """Theta-scheme time stepping exactly as diffhe/heat.py states it (lumped mass; theta = 1 backward Euler,
     theta = 1/2 Crank-Nicolson in incremental form).  f: None, array, or callable t -> array.
     Returns the (n_steps + 1, n) history; with gbar_fn (cotangent of the FINAL state) also
-    (dL/dkappa per element, dL/du0) by the discrete adjoint marched backwards."""
+    (dL/dkappa per element, dL/du0) by the discrete adjoint marched backwards; with_scale=True appends the summed
+    `gradient_scale` of the steps."""
     rd = ReactionDiffusion(nodes, elements, bc_nodes, bc_vals, kappa, 1.0 / (theta * dt))
     n = rd.n
     u = np.array(u0, dtype=np.float64)
@@ -106,11 +113,13 @@ def heat_march(nodes, elements, bc_nodes, bc_vals, kappa, u0, dt, n_steps, f=Non
         return hist
     ubar = np.asarray(gbar_fn(hist[-1]), dtype=np.float64).copy()
     dkappa = np.zeros(rd.elements.shape[0])
+    scale = np.zeros(rd.elements.shape[0])
     for k in reversed(range(n_steps)):
         wbar = ubar if theta == 1.0 else 2.0 * ubar
         lam, dk, _, dload = rd.adjoint(ws[k], wbar)
         dkappa += dk
+        scale += rd.gradient_scale(ws[k], lam)
         prev = rd.mass * rd.c * dload                  # through load = M_L u_k c (Dirichlet rows: lambda = 0)
         ubar = prev if theta == 1.0 else prev - ubar   # u_{k+1} = 2 w - u_k
     ubar[rd.bc_nodes] = 0.0                            # the initial state is overwritten by the Dirichlet values there
-    return hist, dkappa, ubar
+    return (hist, dkappa, ubar, scale) if with_scale else (hist, dkappa, ubar)
