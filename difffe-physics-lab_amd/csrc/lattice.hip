@@ -27,7 +27,11 @@ struct Level {
   const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels (Bv == Bp)
   const unsigned char* bc;  // (n)
   const void* inv;          // optional dense inverse (n, n) of a batch-shared level matrix, in the V-cycle's storage type
+  const double* shift;      // optional (n) batch-shared diagonal shift: A_b = scale_b * K + diag(shift) (reaction term
+                            // c M_L on a FACTORED operator; 0 on Dirichlet rows); NULL = none
 };
+
+__device__ inline double shift_at(const Level& L, int i) { return L.shift ? L.shift[i] : 0.0; }
 
 // 1/d for the smoother: hardware v_rcp_f64 (~2^-23 relative) + one Newton step (~1e-14) -- 4 instructions
 // instead of the ~30 of an IEEE fp64 division.  D^-1 only has to be the same positive diagonal everywhere in
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(256) void dia_apply_dot_kernel(Level L, int Bv, con
   const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   for (int i = nm.node0; i < L.n; i += nm.stride) {
-    const double acc = row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
     const i64 o = (i64)i * Bp + nm.b;
+    const double acc = row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp) + shift_at(L, i) * x[o];
     y[o] = acc;
     s += acc * x[o];
   }
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void dia_residual_kernel(Level L, int Bv, cons
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double bi = (double)bvec[o];
-    const double ri = bi - row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp);
+    const double ri = bi - (row_scale(L, scale, i, nm.b) * dia_row(L, Bv, vb, x, i, nm.b, Bp) + shift_at(L, i) * (double)x[o]);
     if (r) r[o] = (TV)ri;
     s += dot_bx ? bi * (double)x[o] : ri * ri;   // dot_bx: b.x ...
     if (dot_bx) s2 += (double)x[o] * (bi - ri);  // ... and x.(A x): together a lower bound of the solution's energy
@@ -119,11 +123,12 @@ __global__ __launch_bounds__(256) void dia_jacobi_kernel(Level L, int Bv, const 
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double sc = row_scale(L, scale, i, nm.b);
-    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb]);  // same reciprocal as the strip kernels
+    const double sh = shift_at(L, i);
+    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb] + sh);  // same reciprocal as the strip kernels
     const double bi = (double)bvec[o];
     double xo;
     if (xin)
-      xo = (double)xin[o] + omega * (bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp)) * dinv;
+      xo = (double)xin[o] + omega * (bi - (sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp) + sh * (double)xin[o])) * dinv;
     else
       xo = omega * bi * dinv;
     xout[o] = (TV)xo;
@@ -186,7 +191,7 @@ struct Extra {
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
-          bool TAIL>
+          bool TAIL, bool SHIFT = false>
 __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV* __restrict__ src,
                                              const TV* __restrict__ bvec, TV* __restrict__ out, double omega,
                                              double omega_in, const Extra& ex, int Bp, int b, int c0w, int r0,
@@ -221,6 +226,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const TM* __restrict__ p1 = p0 + n * Bv;
   const TM* __restrict__ p2 = p1 + n * Bv;
   const TM* __restrict__ p3 = p2 + n * Bv;
+  const double* __restrict__ psh = SHIFT ? L.shift + i0 : nullptr;   // diagonal shift at (row, c0w): wave-uniform loads
   const TV* __restrict__ px = src + i0 * Bp;
   const TV* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
   TV* __restrict__ po = (out && FUSE != F_RESTRICT) ? out + i0 * Bp : nullptr;
@@ -241,7 +247,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   // `row` is the grid row being loaded; xrow / d0row point at (row, c0w); roff = offset of that
   // row from the current one in vector elements
   auto load_window = [&](int row, i64 roff, const TV* __restrict__ xrow, const TM* __restrict__ d0row,
-                         double* dst) {
+                         double* dst, const double* __restrict__ shrow = nullptr) {
     double ce[RW / 2 + 2], ce2[RW / 2 + 2];
     if (FUSE == F_PROLONG) {  // coarse values around this strip: coarse columns c0w/2 - 1 + j
       const int cr = row >> 1;
@@ -266,7 +272,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       } else {
         v = (double)(xrow + (i64)dq[q] * Bp)[lb];
       }
-      if (XFROMB) v = omega_in * v * fast_rcp(sb * (double)(d0row + (i64)dq[q] * Bv)[lv]);
+      if (XFROMB) v = omega_in * v * fast_rcp(sb * (double)(d0row + (i64)dq[q] * Bv)[lv] + (SHIFT ? shrow[dq[q]] : 0.0));
       if (FUSE == F_PROLONG) {
         double corr;  // c0w is even: window column q has the parity of q + 1
         if (q & 1)
@@ -284,8 +290,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   double n2p[RW], d3p[RW + 1];
 #pragma unroll
   for (int q = 0; q < RW + 2; ++q) xm[q] = 0.0;
-  if (r0 > 0) load_window(r0 - 1, -rowX, px - rowX, p0 - rowV, xm);
-  load_window(r0, 0, px, p0, xc);
+  if (r0 > 0) load_window(r0 - 1, -rowX, px - rowX, p0 - rowV, xm, SHIFT ? psh - W : nullptr);
+  load_window(r0, 0, px, p0, xc, psh);
 #pragma unroll
   for (int k = 0; k < RW; ++k) n2p[k] = (double)(p2 - rowV + (i64)dq[k + 1] * Bv)[lv];
 #pragma unroll
@@ -299,7 +305,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 
   for (int row = r0; row < r1; ++row) {
     if (row + 1 < nyp) {
-      load_window(row + 1, rowX, px + rowX, p0 + rowV, xp);
+      load_window(row + 1, rowX, px + rowX, p0 + rowV, xp, SHIFT ? psh + W : nullptr);
     } else {
 #pragma unroll
       for (int q = 0; q < RW + 2; ++q) xp[q] = 0.0;
@@ -332,8 +338,11 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       acc += n2c[k] * xp[q] + n2p[k] * xm[q];
       if (ND == 4) acc += d3c[k] * xp[q - 1] + d3p[k + 1] * xm[q + 1];
       const i64 o = (i64)k * Bp;
+      const double sh = SHIFT ? psh[dq[k + 1]] : 0.0;   // A = sb K + diag(shift)
+      const double diag = SHIFT ? sb * d0[k] + sh : sb * d0[k];
+      const double Ax = SHIFT ? sb * acc + sh * xc[q] : sb * acc;
       if (MODE == M_APPLY) {
-        double y = sb * acc;
+        double y = Ax;
         if (FUSE == F_NONE && (ex.sub || ex.mask)) {  // load vector of a lattice mesh: F = M f - lift, 0 on Dirichlet rows
           const i64 ig = (i64)row * W + c0w + k;
           if (ex.sub) y -= sub_fac * ex.sub[ig];
@@ -359,10 +368,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           }
         }
       } else {
-        const double dinv = (MODE == M_JACOBI) ? fast_rcp(sb * d0[k]) : 0.0;
+        const double dinv = (MODE == M_JACOBI) ? fast_rcp(diag) : 0.0;
         // XFROMB: the window holds x1 = omega_in * rhs * dinv, so rhs = x1 / (omega_in * dinv)
-        const double bi = XFROMB ? xc[q] * (sb * d0[k]) * inv_omega_in : (double)(pb + o)[lb];
-        const double res = bi - sb * acc;
+        const double bi = XFROMB ? xc[q] * diag * inv_omega_in : (double)(pb + o)[lb];
+        const double res = bi - Ax;
         if (MODE == M_RESID && FUSE == F_RESTRICT) {
           resrow[k] = res;
         } else if (MODE == M_RESID) {
@@ -424,6 +433,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) d3p[k] = d3c[k];
     p0 += rowV; p1 += rowV; p2 += rowV; p3 += rowV;
+    if (SHIFT) psh += W;
     px += rowX;
     if (pb) pb += rowX;
     if (po) po += rowX;
@@ -441,13 +451,17 @@ __device__ inline int xcd_tile(int x, int gx) {
   return k * q + (k < rem ? k : rem) + j;
 }
 
-template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
-          int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void dia_strip_kernel(Level L, const double* __restrict__ scale,
-                                                         const TV* __restrict__ xin, const TV* __restrict__ bvec,
-                                                         TV* __restrict__ out, double omega, double omega_in,
-                                                         Extra ex, double* __restrict__ part, int Bp, int ncb,
-                                                         int TR) {
+// Body of the strip kernels: tile -> (column strip, row chunk) of this wave, the strip march, the per-sample partials.
+// One call level below the __global__ functions on purpose: written directly into the kernel the same code gets a
+// different register allocation for the batch-shared (SHARED) fp64 variants -- 72 VGPRs + 60 B of scratch instead of
+// 62 for the fused CG step, 141-148 instead of 75-95 for the fp64 residual / apply strips -- and the step measures
+// 2 % slower that way (A/B on one MI355X, 1024^2 x 256: 116.1 vs 113.9 ms; fused CG step 1.20 vs 1.17 ms; only the
+// fp64-stored Jacobi sweep of mg fp32=0 prefers the direct form, 1.27 vs 1.31 ms).
+template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW, bool SHIFT>
+__device__ __forceinline__ void strip_kernel_body(Level L, const double* __restrict__ scale,
+                                                  const TV* __restrict__ xin, const TV* __restrict__ bvec,
+                                                  TV* __restrict__ out, double omega, double omega_in, Extra ex,
+                                                  double* __restrict__ part, int Bp, int ncb, int TR) {
   __shared__ double lds[4 * kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -476,11 +490,11 @@ __global__ __launch_bounds__(256, MINW) void dia_strip_kernel(Level L, const dou
   double s = 0.0, s2 = 0.0;
   if (active) {
     if (c0w + RW + 1 > L.W || c0w < 0)
-      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, true>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
-                                                                       c0w, r0, r1, s2);
+      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, true, SHIFT>(L, sb, src, bvec, out, omega, omega_in, ex,
+                                                                              Bp, b, c0w, r0, r1, s2);
     else
-      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, false>(L, sb, src, bvec, out, omega, omega_in, ex, Bp, b,
-                                                                        c0w, r0, r1, s2);
+      s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, false, SHIFT>(L, sb, src, bvec, out, omega, omega_in, ex,
+                                                                               Bp, b, c0w, r0, r1, s2);
   }
   if (part) {
     const double t = block_sum_per_sample(s, Bp, lds);
@@ -490,6 +504,29 @@ __global__ __launch_bounds__(256, MINW) void dia_strip_kernel(Level L, const dou
     const double t = block_sum_per_sample(s2, Bp, lds);
     if (wave == 0) ex.part2[(i64)blockIdx.x * Bp + b] = t;
   }
+}
+
+template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
+          int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void dia_strip_kernel(Level L, const double* __restrict__ scale,
+                                                         const TV* __restrict__ xin, const TV* __restrict__ bvec,
+                                                         TV* __restrict__ out, double omega, double omega_in,
+                                                         Extra ex, double* __restrict__ part, int Bp, int ncb,
+                                                         int TR) {
+  strip_kernel_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, false>(L, scale, xin, bvec, out, omega, omega_in, ex, part,
+                                                                          Bp, ncb, TR);
+}
+
+// The same strips for a FACTORED operator with a batch-shared diagonal shift, A_b = scale_b K_1 + diag(L.shift)
+// (reaction term / heat-equation steps with one scalar kappa per sample): coefficients stay scalar loads.
+template <typename TV, typename TA, int MODE, int FUSE, int ND, bool XFROMB, int RW, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void dia_strip_shift_kernel(Level L, const double* __restrict__ scale,
+                                                               const TV* __restrict__ xin, const TV* __restrict__ bvec,
+                                                               TV* __restrict__ out, double omega, double omega_in,
+                                                               Extra ex, double* __restrict__ part, int Bp, int ncb,
+                                                               int TR) {
+  strip_kernel_body<TV, TA, double, MODE, FUSE, ND, true, XFROMB, RW, true>(L, scale, xin, bvec, out, omega, omega_in, ex, part,
+                                                                           Bp, ncb, TR);
 }
 
 constexpr int kStripCols = 8;
@@ -544,12 +581,18 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 #define STRIP(ND_, SH_, TM_)                                                                                       \
   hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW, MINW>), grid, dim3(256), 0, st, L,   \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
-  if (L.nd == 3) {
+#define STRIP_SHIFT(ND_)                                                                                           \
+  hipLaunchKernelGGL((dia_strip_shift_kernel<TV, TA, MODE, FUSE, ND_, XFROMB, RW, MINW>), grid, dim3(256), 0, st, L, scale, \
+                     xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
+  if (Bv == 1 && L.shift) {
+    if (L.nd == 3) STRIP_SHIFT(3); else STRIP_SHIFT(4);
+  } else if (L.nd == 3) {
     if (Bv == 1) STRIP(3, true, double); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
   } else {
     if (Bv == 1) STRIP(4, true, double); else if (m32) STRIP(4, false, float); else STRIP(4, false, double);
   }
 #undef STRIP
+#undef STRIP_SHIFT
 }
 
 // One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
@@ -568,10 +611,11 @@ __global__ __launch_bounds__(256) void dia_cheby_kernel(Level L, int Bv, const d
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     const double sc = row_scale(L, scale, i, nm.b);
-    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb]);
+    const double sh = shift_at(L, i);
+    const double dinv = fast_rcp(sc * L.v[(i64)i * Bv + vb] + sh);
     const double bi = (double)bvec[o];
     const double xi = xin ? (double)xin[o] : 0.0;
-    const double res = xin ? bi - sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp) : bi;
+    const double res = xin ? bi - (sc * dia_row(L, Bv, vb, xin, i, nm.b, Bp) + sh * xi) : bi;
     const double dn = (din ? c1 * (double)din[o] : 0.0) + c2 * res * dinv;
     dout[o] = (TV)dn;
     const double xo = xi + dn;
@@ -1414,7 +1458,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
@@ -1530,6 +1574,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 #define SCALAR(phase, part, nb_) \
   hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
 
+  for (int l = 0; l < H.nl; ++l)
+    if (H.lev[l].shift && (H.lev[l].inv || Bv != 1)) return DIFFHE_E_BADARG;  // a shift belongs to a factored operator
   if (H.nl == 1 && L0.inv && Bv == 1 && !f32 && L0.n <= kPartBlocks) {
     // DIRECT solve: the whole system is small enough for the dense inverse of its (batch-shared) matrix -- the
     // reference's own regime (2D meshes up to 32 x 32).  x = (1 / s_b) K_1^{-1} b in one launch, then the true residual.
@@ -1789,7 +1835,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (!vals || !x || !y || nx < 2 || ny < 2 || (nd != 3 && nd != 4)) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
-  Level L;
+  Level L{};   // inv, shift: none
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
   const StripGeom g = strip_geom(L, Bp);
   if (g.use && (!sub || sub_B == 1)) {

@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdiffhe_hip.so"))
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
-ABI_VERSION = 4     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
+ABI_VERSION = 5     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
 
 
 class MgLevel(C.Structure):
     """struct diffhe_mg_level (include/diffhe_hip.h)."""
     _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P), ("vals32", _P),
-                ("dense_inv", _P)]
+                ("dense_inv", _P), ("shift", _P)]
 
 
 _LV = C.POINTER(MgLevel)

@@ -142,6 +142,17 @@ class _Engine:
                                                       p.n, p.m, p.W, Bv, st), "diffhe_ell_assemble_rows_ref")
         return vals, lift
 
+    def reaction_shifts(self, c, n_levels):
+        """Per-level (n,) diagonal shifts c * M_L (0 on Dirichlet rows) of a FACTORED lattice operator, cached on the plan."""
+        p = self.p
+        cache = p.__dict__.setdefault("_shift_cache", {})
+        if cache.get("c") != c:
+            cache.clear()
+            cache["c"] = c
+            cache["levels"] = [c * torch.where(lev.is_bc.bool(), torch.zeros_like(lev.lumped_mass()), lev.lumped_mass())
+                               for lev in p.levels]
+        return cache["levels"][:n_levels]
+
     def add_reaction(self, vals, c, lattice):
         """A += c M_L on the free rows (M_L = lumped mass, diagonal): the stored main diagonal is slot 0 of both
         formats.  Lattice: one entry of `vals` per multigrid level, each with its own (re-discretised) lumped mass."""
@@ -257,9 +268,10 @@ class _Engine:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def lattice_levels(self, vals, vals32=None, dense=None):
+    def lattice_levels(self, vals, vals32=None, dense=None, shift=None):
         """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
-        level, whose solve becomes one dense product (diffhe_mg_level.dense_inv)."""
+        level, whose solve becomes one dense product (diffhe_mg_level.dense_inv).  shift = per-level (n,) diagonal
+        shifts of a factored operator (diffhe_mg_level.shift)."""
         nl = len(vals) if dense is None else dense[0] + 1
         arr = (_hip.MgLevel * nl)()
         for i, (lev, v) in enumerate(zip(self.p.levels[:nl], vals[:nl])):
@@ -267,12 +279,13 @@ class _Engine:
             arr[i].vals, arr[i].is_bc = v.data_ptr(), lev.is_bc.data_ptr()
             arr[i].vals32 = vals32[i].data_ptr() if vals32 is not None and vals32[i] is not None else None
             arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
+            arr[i].shift = shift[i].data_ptr() if shift is not None else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None):
         """x0: (n, Bp) initial guess (warm start; left untouched) or None for the cold full-multigrid start."""
         p, L = self.p, self.L
-        arr = self.lattice_levels(vals, vals32, dense)
+        arr = self.lattice_levels(vals, vals32, dense, shift)
         nl = len(arr)
         warm = x0 is not None and x0.shape == (p.n, Bp)
         x = x0.clone() if warm else torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
@@ -482,11 +495,17 @@ def _solve_forward(solver, kappa, f, load=None):
         # cost ~45 launch-bound launches per cycle); a mesh that small as a whole -- the reference's own 2D sizes -- is
         # solved DIRECTLY by that product (level index 0: no iteration at all)
         # a reaction term c M_L does not scale with kappa: K_b + c M_L is assembled per sample (or once, scalar kappa)
-        factored = closed_ and mode in (K_SCALAR, K_SAMPLE) and reaction == 0.0
-        didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1)) else None
-        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_ and reaction == 0.0,
+        factored = closed_ and mode in (K_SCALAR, K_SAMPLE)
+        # a reaction term c M_L does not scale with kappa: a factored operator carries it as a batch-shared diagonal
+        # SHIFT, A_b = kappa_b K_1 + diag(c m) (coefficients stay scalar loads; no cached dense inverse then: it would
+        # depend on c / kappa_b); per-sample matrices get it added to their diagonals
+        didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1) and reaction == 0.0) else None
+        vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_,
                                                                  n_levels=None if didx is None else didx + 1)
-        if reaction:
+        shift = None
+        if reaction and factored:
+            shift = eng.reaction_shifts(reaction, len(vals))
+        elif reaction:
             eng.add_reaction(vals, reaction, lattice=True)
         f_nm = eng.to_node_major(f_dev, B, Bp, n)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
@@ -501,7 +520,8 @@ def _solve_forward(solver, kappa, f, load=None):
                 mg = ctx.mg = dict(mg, fp32=0)        # the direct product runs in fp64
             dense = plan.dense_coarse(didx, vals, bool(mg.get("fp32")))
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense,
-                                              x0=plan.warm.get(("u", Bp)) if solver.warm_start else None)
+                                              x0=plan.warm.get(("u", Bp)) if solver.warm_start else None, shift=shift)
+        ctx.shift = shift
         if solver.warm_start and not bad:
             plan.warm[("u", Bp)] = x                  # never written again: the next solve starts from a copy
         ctx.dense = dense
@@ -583,7 +603,7 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         if ctx.path in ("lattice-mgpcg", "lattice-direct"):
             ws = ctx.solver.warm_start is True
             lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense,
-                                                    x0=plan.warm.get(("lambda", Bp)) if ws else None)
+                                                    x0=plan.warm.get(("lambda", Bp)) if ws else None, shift=ctx.shift)
             if ws and not bad:
                 plan.warm[("lambda", Bp)] = lam
             info.adj_err_est = float(eng.last_est[:B].max())
@@ -597,7 +617,8 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         want_e = mode in (K_ELEM, K_SAMPLE_ELEM)
         dk_nm = dk_sum = None
         if need_k and ctx.path in ("lattice-mgpcg", "lattice-direct") and mode in (K_SCALAR, K_SAMPLE) and Bv == 1 \
-                and not ctx.reaction:
+                and (ctx.factored or not ctx.reaction):   # the bilinear form must see K alone: factored operators keep
+            # the reaction term apart (ctx.shift), assembled ones carry it in `vals`
             dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
             if dk_sum is not None and mode == K_SCALAR and not ctx.factored:
                 dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 4
+#define DIFFHE_ABI_VERSION 5
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -234,6 +234,9 @@ typedef struct diffhe_mg_level {
                                   matrix (identity rows -> zero rows), fp32 when the V-cycle is stored fp32 else
                                   fp64.  The coarsest-level solve is then ONE dense product per cycle (scaled by
                                   1 / scale[b]) instead of the Chebyshev iteration; NULL = Chebyshev */
+  const double* shift;         /* optional (n), batch-shared: the level operator is scale[b] * K + diag(shift) on the
+                                  free rows (reaction term c M_L of a FACTORED operator; must be 0 on Dirichlet rows and
+                                  must not be combined with dense_inv); NULL = none */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the

@@ -201,3 +201,47 @@ def test_heat_equation_example_recovers_conductivities():
     spec.loader.exec_module(mod)
     err, _, _ = mod.main(N=64, B=8, steps=5, n_opt=80, verbose=False)
     assert err < 0.1          # from 0.9 at the start (kappa_0 = 1, kappa_true in [0.5, 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kmode", ["scalar", "sample"])
+def test_factored_reaction_on_strip_kernels_matches_oracle(kmode):
+    """Closed lattice at strip-kernel size with one scalar kappa (per sample): the operator stays FACTORED,
+    A_b = kappa_b K_1 + diag(c m) with the reaction term as a batch-shared diagonal shift (`diffhe_mg_level.shift`,
+    `dia_strip_shift_kernel`); u, dL/dkappa (bilinear-form shortcut: must see K_1 alone), dL/df, dL/dload against
+    the oracle on the first, a middle and the last sample."""
+    from diffhe.plan import get_plan
+    mesh = FEMesh.rectangle(260, 210, (0.0, 1.3), (0.0, 1.0), 0.3)
+    nodes, el, bn, bv = _arrays(mesh)
+    n, B, c = mesh.n_nodes, 64, 40.0
+    rng = np.random.default_rng(21)
+    kap = np.array(1.7) if kmode == "scalar" else rng.uniform(0.5, 2.0, B)
+    f = 1.0 + 0.5 * rng.standard_normal((B, n))
+    load = 0.1 * rng.standard_normal((B, n)) * ho.lumped_mass(nodes, el)
+    kt = torch.from_numpy(np.asarray(kap)).cuda().requires_grad_(True)
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    lt = torch.from_numpy(load).cuda().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt, reaction=c)
+    u = solver(ft, load=lt)
+    (u ** 2).sum().backward()
+    assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.not_converged == 0
+    assert get_plan(mesh, torch.device("cuda", 0))._shift_cache["c"] == c          # the factored form was used
+    dk_all = 0.0
+    for b in (0, B // 2, B - 1):
+        kb = float(kap) if kmode == "scalar" else kap[b]
+        rd = ho.ReactionDiffusion(nodes, el, bn, bv, kb, c)
+        uo = rd.solve(f[b], load=load[b])
+        lam, dko, dfo, dlo = rd.adjoint(uo, 2.0 * uo)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(ft.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
+        assert rel_err(lt.grad[b].cpu().numpy(), dlo) < RTOL_GRAD
+        if kmode == "sample":
+            assert abs(float(kt.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
+        dk_all += dko.sum()
+    if kmode == "scalar":      # the shared kappa's gradient sums over ALL samples: compare through the identity instead
+        # dL/dkappa = -sum_b lambda_b^T K_1 u_b; with K_1 u = (F - c M u) / kappa on the free rows it equals
+        # -(1 / kappa) sum_b lambda_b^T (F_b - lift - c M u_b): checked on the three oracle samples by linearity
+        k2 = torch.tensor(1.7, dtype=T64, device="cuda", requires_grad=True)
+        u2 = DifferentiableFESolver(mesh, k2, reaction=c)(ft.detach()[[0, B // 2, B - 1]], load=lt.detach()[[0, B // 2, B - 1]])
+        (u2 ** 2).sum().backward()
+        assert abs(float(k2.grad) - dk_all) < RTOL_GRAD * abs(dk_all)
