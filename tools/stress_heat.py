@@ -81,8 +81,10 @@ for case in range(n_cases):
         info, tag = solver.last_info, f"c={c:.1e}"
         for b in check:
             rd = ho.ReactionDiffusion(nodes, el, bn, bv, kap if kmode in ("scalar", "elem") else kap[b], c)
-            uo = rd.solve(f[b], load=load[b])
-            lam, dko, dfo, dlo = rd.adjoint(uo, 2 * uo)
+            # refine=2: near-singular operators (no Dirichlet node, small c: cond 1e8-1e9) leave the plain LU result
+            # 2e-10 from the exact solution of its own matrix (seed 26 case 4: HIP 8e-12 from it)
+            uo = rd.solve(f[b], load=load[b], refine=2)
+            lam, dko, dfo, dlo = rd.adjoint(uo, 2 * uo, refine=2)
             errs += [rel(u[b].detach().numpy(), uo), rel(ft.grad[b].numpy(), dfo), rel(lt.grad[b].numpy(), dlo)]
             # gradients are judged against the magnitude of the terms they are made of (tools/stress.py): with no
             # Dirichlet node and a reaction term u ~ f / c is nearly constant and the terms of dL/dkappa_e cancel
@@ -117,7 +119,11 @@ for case in range(n_cases):
         print("per-check errors", ["%.1e" % v for v in errs])
         print(info, "n_bc", len(bn))
     worst = max(worst, e)
-    flag = "" if e < 1e-10 else "   <-- ABOVE 1e-10"
+    # no Dirichlet node + small reaction coefficient: within c * m of singular (cond 1e8-1e9), 1e-10 is beyond fp64 for
+    # any solver there (tests/test_heat_equation.py::test_near_singular_...): judged at 2e-9
+    near_singular = len(bn) == 0 and what == "reaction" and c < 1.0
+    lim = 2e-9 if near_singular else 1e-10
+    flag = ("   (near-singular: limit 2e-9)" if near_singular else "") if e < lim else f"   <-- ABOVE {lim:g}"
     print(f"case {case:3d} {kind:12s} n={n:6d} B={B:3d} kappa={kmode:11s} {what:8s} {tag:16s} path={info.path:14s} "
           f"iters={info.iterations:4d} err={e:.1e}{flag}", flush=True)
 print("worst", worst)
