@@ -406,7 +406,7 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
                  ("dia_strip_kernel<M_JACOBI> (sweep)", 3.0 * tv * n * Bp)]
         # HBM bytes per launch from the committed PMC passes (NOT measured in this run): profiles/r02_pmc_traffic.json,
         # keyed by kernel symbol (fp32 V-cycle storage, shared matrix, 1024^2 x 256)
-        pmc_keys = [None, "pcg_update_kernel", "dia_strip_kernel<float, float, double, 2, 0, 3, true, true",
+        pmc_keys = ["dia_strip_kernel<double, float, double, 0, 4", "pcg_update_kernel", "dia_strip_kernel<float, float, double, 2, 0, 3, true, true",
                     "dia_strip_kernel<float, float, double, 1, 3", "dia_strip_kernel<float, float, double, 2, 1",
                     "dia_strip_kernel<float, float, double, 2, 0, 3, true, false"]
         pmc_tab = {}
