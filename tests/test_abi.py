@@ -37,3 +37,30 @@ def test_binding_and_header_agree_on_the_abi_version():
     import re
     m = re.search(r"#define\s+DIFFHE_ABI_VERSION\s+(\d+)", open(HEADER).read())
     assert m and int(m.group(1)) == _hip.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of the two structs that cross the boundary, as a C compiler sees the header, against the ctypes
+    mirrors in diffhe/_hip.py (the header is plain C: gcc compiles it without HIP)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    fields = {"diffhe_mg_level": [f for f, _ in _hip.MgLevel._fields_], "diffhe_amg_level": [f for f, _ in _hip.AmgLevel._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for struct, names in fields.items():
+        lines.append(f'  printf("{struct} %zu", sizeof({struct}));')
+        for f in names:
+            lines.append(f'  printf(" %zu", offsetof({struct}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line, (struct, cls) in zip(out, (("diffhe_mg_level", _hip.MgLevel), ("diffhe_amg_level", _hip.AmgLevel))):
+        nums = [int(v) for v in line.split()[1:]]
+        assert line.split()[0] == struct
+        assert nums[0] == ctypes.sizeof(cls)
+        assert nums[1:] == [getattr(cls, f).offset for f, _ in cls._fields_]
