@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
       double v = 0.0;
       for (int c = c0; c < c1; ++c) {
         const int code = contrib[c];
-        const int e = code >> 4, pq = code & 15;
+        const int e = code >> 6, pq = code & 63;   // local entry p * npe + q: < 9 for P1 triangles, < 36 for P2
         const double kap = kappa ? kappa[(i64)e * kse + (i64)nm.b * ksb] : 1.0;
         if (REF) {
           const double num = kap * local[(i64)pq * m + e];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void grad_kappa_kernel(const int* __restrict__
   double s = 0.0;
   if (ok)
     for (int e = nm.node0; e < m; e += nm.stride) {
-      double le[3], ue[3];
+      double le[6], ue[6];   // npe <= 6 (P2 triangles)
       for (int p = 0; p < npe; ++p) {
         const int node = elems[(i64)p * m + e];
         const i64 o = (i64)node * Bp + nm.b;
@@ -1059,7 +1059,7 @@ extern "C" int diffhe_grad_kappa_blocks(int m, int Bp) { return (int)diffhe::nod
 extern "C" int diffhe_p1_grad_kappa(const int* elems, const double* k0, const double* lam, const double* u,
                                     const double* g, int npe, int m, int Bp, double* dk_e, double* dk_part,
                                     double* dk_sum, void* stream) {
-  if (!elems || !k0 || !lam || !u || !dk_part || !dk_sum || (npe != 2 && npe != 3) || m < 1) return DIFFHE_E_BADARG;
+  if (!elems || !k0 || !lam || !u || !dk_part || !dk_sum || (npe != 2 && npe != 3 && npe != 6) || m < 1) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   const dim3 grid = diffhe::node_grid(m, Bp);
   diffhe::account(8.0 * Bp * (2.0 * m * (npe == 3 ? 0.5 : 1.0) + (dk_e ? m : 0)));  // lambda and u once per node, dk per element

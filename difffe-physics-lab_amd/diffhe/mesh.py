@@ -70,6 +70,31 @@ class FEMesh:
         bc = dict.fromkeys(np.nonzero(on_edge)[0].tolist(), bc_value)
         return cls(nodes=torch.from_numpy(coords), elements=torch.from_numpy(tris), dirichlet_nodes=bc)
 
+    @classmethod
+    def rectangle_p2(cls, nx: int = 4, ny: int = 4, x_range: Tuple[float, float] = (0.0, 1.0),
+                     y_range: Tuple[float, float] = (0.0, 1.0), bc_value: float = 0.0) -> "FEMesh":
+        """QUADRATIC (P2, 6-node) triangles on the triangulation of `rectangle(nx, ny)` -- ours: "P2 elements" is an
+        item of the reference's README roadmap (README.md:139-143), it has no such factory.  Nodes = the
+        (2 nx + 1) x (2 ny + 1) lattice of vertices and edge midpoints, id = row * (2 nx + 1) + col (vertices sit at
+        even row and column); each quad (a, b, c, d) gives [a, b, d, ab, bd, da] then [b, c, d, bc, cd, db]
+        (three vertices, then the midpoints of edges 0-1, 1-2, 2-0); Dirichlet on the whole boundary."""
+        Wn = 2 * nx + 1
+        xs = np.linspace(x_range[0], x_range[1], Wn)
+        ys = np.linspace(y_range[0], y_range[1], 2 * ny + 1)
+        gx, gy = np.meshgrid(xs, ys)
+        coords = np.stack([gx.ravel(), gy.ravel()], axis=1)
+        row, col = np.divmod(np.arange(nx * ny, dtype=np.int64), nx)
+        a = 2 * row * Wn + 2 * col                   # vertex a of quad (row, col) in the fine numbering
+        b, d, c = a + 2, a + 2 * Wn, a + 2 * Wn + 2
+        ab, da, bd, bc, cd = a + 1, a + Wn, a + Wn + 1, a + Wn + 2, a + 2 * Wn + 1
+        tris = np.empty((2 * nx * ny, 6), dtype=np.int64)
+        tris[0::2] = np.stack([a, b, d, ab, bd, da], axis=1)
+        tris[1::2] = np.stack([b, c, d, bc, cd, bd], axis=1)
+        on_edge = (np.isclose(coords[:, 0], x_range[0]) | np.isclose(coords[:, 0], x_range[1])
+                   | np.isclose(coords[:, 1], y_range[0]) | np.isclose(coords[:, 1], y_range[1]))
+        bc_ = dict.fromkeys(np.nonzero(on_edge)[0].tolist(), bc_value)
+        return cls(nodes=torch.from_numpy(coords), elements=torch.from_numpy(tris), dirichlet_nodes=bc_)
+
     # -- convenience ---------------------------------------------------------------
     def free_nodes(self) -> List[int]:
         """Ascending ids of the unconstrained nodes (reference mesh.py:127-129)."""

@@ -99,14 +99,14 @@ def build_ell_pattern(elements: np.ndarray, n: int):
     inv = np.empty(len(order), dtype=np.int64)
     inv[order] = np.arange(len(order))
     contrib_entry = ell_index[entry_id[inv[n:]]]             # ELL index of each (e, pq)
-    code = (e_idx * 16 + pq).astype(np.int64)
+    code = (e_idx * 64 + pq).astype(np.int64)                # decoded by assemble_rows_kernel: e = code >> 6
     corder = np.argsort(contrib_entry, kind="stable")        # fixed order: deterministic sums
     contrib = code[corder].astype(np.int32)
     counts = np.bincount(contrib_entry, minlength=W * n)
     ent_ptr = np.zeros(W * n + 1, dtype=np.int64)
     np.cumsum(counts, out=ent_ptr[1:])
     slot_of = (contrib_entry // n).reshape(m, nloc).T.copy().astype(np.int32)
-    if ent_ptr[-1] >= 2 ** 31 or m >= 2 ** 27:
+    if ent_ptr[-1] >= 2 ** 31 or m >= 2 ** 25:
         raise ValueError("mesh too large for int32 gather lists")
     return dict(W=W, cols=ell_cols.reshape(W, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib,
                 slot_of=slot_of)
@@ -144,7 +144,7 @@ def build_dia_pattern(nx: int, ny: int):
     Seven entries per row in the fixed order offsets (0, +1, +W, +nx, -1, -W, -nx), W = nx+1;
     the first four can be stored (store_slot), the lower three only feed the Dirichlet lift.  The contributions
     of an entry are listed in ELEMENT ORDER (then local-entry order): the order the reference's loop adds them.
-    Returns dict(We=7, cols (7,n) i32, ent_ptr (7n+1) i32, contrib i32 packed e * 16 + p * 3 + q)."""
+    Returns dict(We=7, cols (7,n) i32, ent_ptr (7n+1) i32, contrib i32 packed e * 64 + p * 3 + q)."""
     n, W = (nx + 1) * (ny + 1), nx + 1
     r, c = np.divmod(np.arange(n, dtype=np.int64), W)
     up, dn, lf, rt = r < ny, r >= 1, c >= 1, c < nx          # a quad exists above / below / left / right of the node
@@ -168,7 +168,7 @@ def build_dia_pattern(nx: int, ny: int):
     ar = np.arange(n, dtype=np.int32)
     for k, (off, cands) in enumerate(kinds):
         valid = np.stack([v for v, _, _ in cands], axis=1)                           # (n, C)
-        codes = np.stack([(e * 16 + pq).astype(np.int32) for _, e, pq in cands], axis=1)
+        codes = np.stack([(e * 64 + pq).astype(np.int32) for _, e, pq in cands], axis=1)
         cnt = valid.sum(axis=1, dtype=np.int32)
         counts[k * n:(k + 1) * n] = cnt
         np.copyto(cols[k * n:(k + 1) * n], ar + np.int32(off), where=cnt > 0)
@@ -197,7 +197,7 @@ def _build_dia_pattern_sorted(nx: int, ny: int):
     ell_cols = np.tile(np.arange(n, dtype=np.int32), 7)
     ell_cols[ent] = cols.astype(np.int32)
     order = np.argsort(ent, kind="stable")
-    contrib = (e_idx * 16 + pq)[order].astype(np.int32)
+    contrib = (e_idx * 64 + pq)[order].astype(np.int32)
     ent_ptr = np.zeros(7 * n + 1, dtype=np.int64)
     np.cumsum(np.bincount(ent, minlength=7 * n), out=ent_ptr[1:])
     return dict(We=7, cols=ell_cols.reshape(7, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib)
@@ -243,6 +243,33 @@ def reference_order_integrals(coords: np.ndarray, elems: np.ndarray):
     t = (b[:, None, :] * b[None, :, :] + c[:, None, :] * c[None, :, :]).reshape(9, -1)
     t[:, ~keep] = 0.0
     return t, np.where(keep, 4.0 * area, 1.0)
+
+
+def p2_element_integrals(nodes: np.ndarray, elements: np.ndarray):
+    """(k0 (36, m), m0 (36, m)) of straight-sided 6-node triangles [v0, v1, v2, m01, m12, m20]: unit-kappa stiffness
+    int grad phi_p . grad phi_q (3-point edge-midpoint rule: exact, the integrand is quadratic) and the consistent mass
+    int phi_p phi_q (closed form).  phi_i = L_i (2 L_i - 1), phi_ij = 4 L_i L_j in barycentric coordinates L."""
+    v = nodes[elements[:, :3]]                                   # (m, 3, 2)
+    xi, yi, xj, yj, xk, yk = v[:, 0, 0], v[:, 0, 1], v[:, 1, 0], v[:, 1, 1], v[:, 2, 0], v[:, 2, 1]
+    det = (xj - xi) * (yk - yi) - (xk - xi) * (yj - yi)
+    area = 0.5 * np.abs(det)
+    keep = area >= 1e-15                                         # degenerate triangles contribute nothing (solver.py:120)
+    safe = np.where(keep, det, 1.0)
+    gL = np.stack([np.stack([yj - yk, xk - xj], axis=1), np.stack([yk - yi, xi - xk], axis=1),
+                   np.stack([yi - yj, xj - xi], axis=1)], axis=1) / safe[:, None, None]      # grad L_i, (m, 3, 2)
+    k0 = np.zeros((len(elements), 6, 6))
+    for L in ((0.5, 0.5, 0.0), (0.0, 0.5, 0.5), (0.5, 0.0, 0.5)):
+        G = np.empty((len(elements), 6, 2))
+        for i in range(3):
+            G[:, i] = (4.0 * L[i] - 1.0) * gL[:, i]
+        for e_, (i, j) in enumerate(((0, 1), (1, 2), (2, 0))):
+            G[:, 3 + e_] = 4.0 * (L[i] * gL[:, j] + L[j] * gL[:, i])
+        k0 += np.einsum("epd,eqd->epq", G, G) * (area / 3.0)[:, None, None]
+    k0[~keep] = 0.0
+    Mref = np.array([[6, -1, -1, 0, -4, 0], [-1, 6, -1, 0, 0, -4], [-1, -1, 6, -4, 0, 0],
+                     [0, 0, -4, 32, 16, 16], [-4, 0, 0, 16, 32, 16], [0, -4, 0, 16, 16, 32]], dtype=np.float64) / 180.0
+    m0 = Mref[None] * np.where(keep, area, 0.0)[:, None, None]
+    return (np.ascontiguousarray(k0.reshape(-1, 36).T), np.ascontiguousarray(m0.reshape(-1, 36).T))
 
 
 def _lumped_mass(nodes: np.ndarray, elements: np.ndarray) -> np.ndarray:
@@ -325,13 +352,14 @@ class SolvePlan:
         self.dim = mesh.dim
         self.n = mesh.n_nodes
         self.m = mesh.n_elements
-        self.npe = self.dim + 1
+        self.npe = int(mesh.elements.shape[1])                        # 2 (1D), 3 (P1 triangles) or 6 (P2 triangles)
         if self.dim not in (1, 2):
             raise NotImplementedError("Only 1D and 2D supported")  # reference solver.py:67
         nodes = mesh.nodes.detach().to("cpu", torch.float64).numpy()
         elements = mesh.elements.detach().to("cpu", torch.int64).numpy()
-        if elements.shape[1] != self.npe:
-            raise ValueError(f"expected {self.npe} nodes per element, got {elements.shape[1]}")
+        if self.npe != self.dim + 1 and not (self.dim == 2 and self.npe == 6):
+            raise ValueError(f"expected {self.dim + 1} nodes per element (or 6: P2 triangles), got {self.npe}")
+        self.is_p2 = self.npe == 6
         is_bc, g = _bc_arrays(mesh)
         self.n_bc = int(is_bc.sum())
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
@@ -434,13 +462,18 @@ class SolvePlan:
         self.slot_of = dev(pat["slot_of"])
         stream = _stream(device)
         nloc = self.npe * self.npe
-        self.k0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
-        self.m0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
-        _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), self.dim, self.n,
-                                                 self.m, _hip.ptr(self.k0), _hip.ptr(self.m0), stream),
-                   "diffhe_p1_element_integrals")
-        tn, dn = reference_order_integrals(self.coords.cpu().numpy(), self.elems.cpu().numpy())
-        self.tnum, self.den = dev(tn), dev(dn)       # reference-order assembly
+        if self.is_p2:      # quadratic triangles (ours): batch-shared integrals from the host, plain kappa * k0 assembly
+            k0h, m0h = p2_element_integrals(self._nodes_host, self._elements)
+            self.k0, self.m0 = dev(k0h), dev(m0h)
+            self.tnum = self.den = None
+        else:
+            self.k0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
+            self.m0 = torch.empty((nloc, self.m), dtype=torch.float64, device=device)
+            _hip.check(L.diffhe_p1_element_integrals(_hip.ptr(self.coords), _hip.ptr(self.elems), self.dim, self.n,
+                                                     self.m, _hip.ptr(self.k0), _hip.ptr(self.m0), stream),
+                       "diffhe_p1_element_integrals")
+            tn, dn = reference_order_integrals(self.coords.cpu().numpy(), self.elems.cpu().numpy())
+            self.tnum, self.den = dev(tn), dev(dn)       # reference-order assembly
         # load matrix M (batch-shared ELL values): F = M f, df = M^T lambda
         self.Mvals = torch.empty((self.W, self.n), dtype=torch.float64, device=device)
         _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self.m0), None, 0, 0, _hip.ptr(self.ent_ptr),

@@ -124,7 +124,13 @@ class _Engine:
         st = _stream(p.device)
         vals = torch.empty((p.W, p.n, Bv), dtype=torch.float64, device=p.device)
         lift = torch.empty((p.n, Bv), dtype=torch.float64, device=p.device)
-        if self.assembly == "atomic" and Bv > 1:
+        if p.is_p2:
+            # quadratic triangles (ours; no reference operator to be bit-identical with): kappa * k0, gathered
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(p.k0), _hip.ptr(kdev), kse, ksb, _hip.ptr(p.ent_ptr),
+                                                  _hip.ptr(p.contrib), _hip.ptr(p.cols), None, _hip.ptr(p.is_bc),
+                                                  _hip.ptr(p.g), _hip.ptr(vals), _hip.ptr(lift), p.n, p.m, p.W, Bv, st),
+                       "diffhe_ell_assemble_rows(P2)")
+        elif self.assembly == "atomic" and Bv > 1:
             vals.zero_()
             _hip.check(L.diffhe_ell_assemble_atomic(_hip.ptr(p.coords), _hip.ptr(p.elems), p.dim, _hip.ptr(kdev), kse,
                                                     ksb, _hip.ptr(p.slot_of), _hip.ptr(vals), p.n, p.m, p.W, Bv, st),
@@ -460,6 +466,8 @@ def _solve_forward(solver, kappa, f, load=None):
     ctx.load_batched = load is not None and load.dim() == 2
     ctx.reaction = reaction
     # the scan solver inverts a pure path-graph Laplacian: with a reaction term the chain takes the general path
+    if reaction and plan.is_p2:
+        raise NotImplementedError("reaction term with P2 elements: the lumped P2 mass vanishes at the vertices")
     use_chain = plan.is_chain and reaction == 0.0
     if use_chain and load_dev is not None:
         # the 1D load map of solver.py:95-96 is diagonal (h/2 from each side): an extra load is a change of forcing

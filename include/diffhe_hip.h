@@ -116,7 +116,7 @@ int diffhe_p1_element_integrals(const double* coords, const int* elems, int dim,
  *   local     (npe*npe, m) local matrices (k0 or m0)
  *   kappa     kappa[e*kappa_se + b*kappa_sb] or NULL for kappa == 1
  *   ent_ptr   (n*W + 1) CSR over ELL entries (row i, slot k) -> contributions
- *   contrib   packed (e * 16 + p*npe+q)
+ *   contrib   packed (e * 64 + p*npe+q), npe <= 6
  *   cols      (W, n) column id of entry (row i, k) at k*n + i; entry 0 = diagonal;
  *             unused entries point at the row itself
  *   store_slot (W) or NULL: entry k is stored at vals[(store_slot[k], i, b)]; -1 = not

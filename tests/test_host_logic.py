@@ -72,7 +72,7 @@ def _emulate_gather(pat, local, kappa_e, n):
     W, cols, ptr, contrib = pat["W"], pat["cols"], pat["ent_ptr"], pat["contrib"]
     m = local.shape[1]
     K = np.zeros((n, n))
-    e, pq = contrib >> 4, contrib & 15
+    e, pq = contrib >> 6, contrib & 63
     term = kappa_e[e] * local[pq, e]
     ent_of = np.repeat(np.arange(W * n), np.diff(ptr))
     vals = np.bincount(ent_of, weights=term, minlength=W * n)
@@ -122,7 +122,7 @@ def test_dia_pattern_reproduces_dense_assembly(nx, ny):
     k0, _ = orc.element_matrices(nodes, elements)
     local = k0.reshape(len(elements), 9).T.copy()
     kap = rng.uniform(0.5, 2.0, len(elements))
-    e, pq = pat["contrib"] >> 4, pat["contrib"] & 15
+    e, pq = pat["contrib"] >> 6, pat["contrib"] & 63
     ent_of = np.repeat(np.arange(7 * n), np.diff(pat["ent_ptr"]))
     vals = np.bincount(ent_of, weights=kap[e] * local[pq, e], minlength=7 * n).reshape(7, n)
     Kref, _ = orc.assemble_dense(nodes, elements, kap, np.zeros(n))

@@ -322,3 +322,49 @@ def test_heat_oracle_adjoint_matches_finite_differences(theta):
         d = np.zeros(len(nodes)); d[i] = 1e-6
         assert abs((L(kap, u0 + d) - L(kap, u0 - d)) / 2e-6 - du0[i]) < 1e-7 * max(1.0, abs(du0[i]))
     assert np.all(du0[bn] == 0.0)
+
+
+# ---- P2 (quadratic triangle) oracle (oracle/p2_oracle.py): no reference counterpart, closed forms instead ----
+def test_p2_oracle_reproduces_quadratic_solutions_exactly():
+    """A solution that lies in the P2 space is reproduced to rounding: u = x (1.5 - x) / 2 + y (1 - y) has -lap u = 3
+    and non-zero Dirichlet data; also the host integrals of the product against the oracle's quadrature."""
+    from oracle import p2_oracle as p2
+    from diffhe import FEMesh
+    from diffhe.plan import p2_element_integrals
+    nodes, el, bn, _ = p2.mesh_rectangle_p2(5, 4, (0.0, 1.5), (0.0, 1.0))
+    mesh = FEMesh.rectangle_p2(5, 4, (0.0, 1.5), (0.0, 1.0))
+    assert np.array_equal(mesh.nodes.numpy(), nodes) and np.array_equal(mesh.elements.numpy(), el)
+    assert np.array_equal(np.fromiter(mesh.dirichlet_nodes.keys(), dtype=np.int64), bn)
+    exact = lambda x, y: x * (1.5 - x) / 2 + y * (1 - y)      # noqa: E731
+    ue = exact(nodes[:, 0], nodes[:, 1])
+    prob = p2.P2Problem(nodes, el, bn, ue[bn], 1.7)
+    u = prob.solve(np.full(len(nodes), 3.0 * 1.7))
+    assert rel_err(u, ue) < 1e-13
+    k0, m0 = p2_element_integrals(nodes, el)
+    assert np.abs(k0.T.reshape(-1, 6, 6) - prob.k0).max() < 1e-13
+    assert np.abs(m0.T.reshape(-1, 6, 6) - prob.m0).max() < 1e-16
+
+
+def test_p2_oracle_third_order_convergence_and_adjoint():
+    """-lap u = 2 pi^2 sin(pi x) sin(pi y): the L2 error falls by ~8 per halving of h (P1: 4); the adjoint against
+    central differences in a per-element kappa."""
+    from oracle import p2_oracle as p2
+    exact = lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y)      # noqa: E731
+    errs = []
+    for N in (4, 8, 16):
+        nodes, el, bn, bv = p2.mesh_rectangle_p2(N, N)
+        prob = p2.P2Problem(nodes, el, bn, bv, 1.0)
+        u = prob.solve(2 * np.pi ** 2 * exact(nodes[:, 0], nodes[:, 1]))
+        errs.append(prob.l2_error(u, exact))
+    assert 6.0 < errs[0] / errs[1] < 12.0 and 6.5 < errs[1] / errs[2] < 10.0
+    nodes, el, bn, bv = p2.mesh_rectangle_p2(3, 3, (0.0, 1.0), (0.0, 1.0), 0.2)
+    rng = np.random.default_rng(5)
+    kap = np.exp(0.3 * rng.standard_normal(len(el)))
+    f = 1.0 + rng.standard_normal(len(nodes))
+    L = lambda k_: float(np.sum(p2.P2Problem(nodes, el, bn, bv, k_).solve(f) ** 2))      # noqa: E731
+    prob = p2.P2Problem(nodes, el, bn, bv, kap)
+    u = prob.solve(f)
+    dk, df = prob.adjoint(u, 2 * u)
+    for e in (0, 7, len(el) - 1):
+        d = np.zeros(len(el)); d[e] = 1e-6
+        assert abs((L(kap + d) - L(kap - d)) / 2e-6 - dk[e]) < 1e-7 * max(1.0, abs(dk[e]))
