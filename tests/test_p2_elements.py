@@ -110,3 +110,42 @@ def test_p2_batch_at_a_larger_size():
         dko, _ = prob.adjoint(uo, 2.0 * uo)
         assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
         assert abs(float(kappa.grad[b]) - dko.sum()) < RTOL_GRAD * abs(dko.sum())
+
+
+@pytest.mark.gpu
+def test_p2_on_a_distorted_renumbered_mesh_with_partial_dirichlet_boundary():
+    """Not only the factory's lattice: vertices jittered (edge midpoints moved with them, sides stay straight), nodes and
+    elements in random order, Dirichlet data on the left edge only (Neumann elsewhere), one kappa field per sample."""
+    base = FEMesh.rectangle_p2(11, 8, (0.0, 1.4), (0.0, 1.0))
+    rng = np.random.default_rng(23)
+    x = base.nodes.numpy().copy()
+    el = base.elements.numpy()
+    Wn, Hn = 2 * 11 + 1, 2 * 8 + 1
+    grid = x.reshape(Hn, Wn, 2)
+    hx, hy = 1.4 / 11, 1.0 / 8
+    grid[2:-2:2, 2:-2:2] += rng.uniform(-0.2, 0.2, grid[2:-2:2, 2:-2:2].shape) * np.array([hx, hy])   # interior vertices
+    for a, b, mid in ((0, 1, 3), (1, 2, 4), (2, 0, 5)):
+        x[el[:, mid]] = 0.5 * (x[el[:, a]] + x[el[:, b]])
+    perm = rng.permutation(len(x))
+    nodes = np.empty_like(x)
+    nodes[perm] = x
+    el2 = perm[el][rng.permutation(len(el))]
+    left = [int(perm[k]) for k in base.dirichlet_nodes if abs(float(base.nodes[k, 0])) < 1e-12]
+    mesh = FEMesh(torch.from_numpy(nodes), torch.from_numpy(el2), {k: 0.4 for k in left})
+    bn, bv = np.asarray(left, dtype=np.int64), np.full(len(left), 0.4)
+    B, m, n = 5, mesh.n_elements, mesh.n_nodes
+    kap = np.exp(0.4 * rng.standard_normal((B, m)))
+    f = 1.0 + 0.5 * rng.standard_normal((B, n))
+    kt = torch.from_numpy(kap).cuda().requires_grad_(True)
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kt)
+    u = solver(ft)
+    (u ** 2).sum().backward()
+    assert solver.last_info.not_converged == 0
+    for b in (0, B - 1):
+        prob = p2.P2Problem(nodes, el2, bn, bv, kap[b])
+        uo = prob.solve(f[b])
+        dko, dfo = prob.adjoint(uo, 2.0 * uo)
+        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
+        assert rel_err(kt.grad[b].cpu().numpy(), dko) < RTOL_GRAD
+        assert rel_err(ft.grad[b].cpu().numpy(), dfo) < RTOL_GRAD
