@@ -446,6 +446,45 @@ __global__ __launch_bounds__(256) void grad_kappa_kernel(const int* __restrict__
   if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) dk_part[(i64)blockIdx.x * Bp + nm.b] = t;
 }
 
+// The same contraction summed over the batch, for a kappa field SHARED by all samples (kappa (m,)):
+//   dk[e] = sum_b dk[e, b].  One wave per element at a time; its lanes walk the sample chunks in a fixed order and
+// meet in a fixed-order wave reduction, so the result is bitwise reproducible and the (m, Bp) per-sample gradient
+// (4.3 GB at 1024^2 x 256) is never written.
+__global__ __launch_bounds__(256) void grad_kappa_shared_kernel(const int* __restrict__ elems,
+                                                                 const double* __restrict__ k0,
+                                                                 const double* __restrict__ lam,
+                                                                 const double* __restrict__ u,
+                                                                 const double* __restrict__ g, int npe, int m, int B,
+                                                                 int Bp, double* __restrict__ dk) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int e = blockIdx.x * 4 + wave; e < m; e += gridDim.x * 4) {
+    int node[6];
+    double gq[6], kk[36];
+    for (int p = 0; p < npe; ++p) {
+      node[p] = elems[(i64)p * m + e];
+      gq[p] = g ? g[node[p]] : 0.0;
+    }
+    for (int pq = 0; pq < npe * npe; ++pq) kk[pq] = k0[(i64)pq * m + e];
+    double s = 0.0;
+    for (int b = lane; b < B; b += kWave) {   // padding samples (b >= B) carry no gradient
+      double le[6], ue[6];
+      for (int p = 0; p < npe; ++p) {
+        const i64 o = (i64)node[p] * Bp + b;
+        le[p] = lam[o];
+        ue[p] = u[o] + gq[p];
+      }
+      double acc = 0.0;
+      for (int p = 0; p < npe; ++p)
+        for (int q = 0; q < npe; ++q) acc += le[p] * kk[p * npe + q] * ue[q];
+      s -= acc;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) dk[e] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int nblk, int Bp,
                                                             double* __restrict__ out) {
   __shared__ double lds[4 * kWave];
@@ -1067,6 +1106,18 @@ extern "C" int diffhe_p1_grad_kappa(const int* elems, const double* k0, const do
                      dk_e, dk_part);
   hipLaunchKernelGGL(sum_partials_kernel, dim3((Bp + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)dk_part, (int)grid.x, Bp, dk_sum);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_p1_grad_kappa_shared(const int* elems, const double* k0, const double* lam, const double* u,
+                                           const double* g, int npe, int m, int B, int Bp, double* dk, void* stream) {
+  if (!elems || !k0 || !lam || !u || !dk || (npe != 2 && npe != 3 && npe != 6) || m < 1 || B < 1 || B > Bp) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  long long blocks = ((long long)m + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  diffhe::account(8.0 * (Bp * 2.0 * m * (npe == 3 ? 0.5 : 1.0) + m));  // lambda and u once per node, dk once per element
+  hipLaunchKernelGGL(grad_kappa_shared_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, elems, k0, lam, u,
+                     g, npe, m, B, Bp, dk);
   return diffhe::check_launch();
 }
 

@@ -916,6 +916,7 @@ struct PcgScalars {
   double* est;            // out: last estimate sqrt(r.z / energy) per sample
   double tol_e2;          // 0: residual criterion only
   int have_energy;        // energy[] was set from the full-multigrid start (S_ENERGY)
+  int* rule;              // out: which rule ended each sample: 0 none (iteration cap), 1 residual, 2 energy-norm estimate
 };
 enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6, S_FLOOR = 7, S_ENERGY = 8,
        S_ENERGY2 = 9 };
@@ -951,6 +952,7 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
       if (S.rs) S.rs[b] = a > 0.0 ? ldexp(1.0, -ilogb(sqrt(a))) : 1.0;  // rs |b| in [1, 2)
       S.tol2[b] = tol * tol * a;
       S.active[b] = a > 0.0 ? 1 : 0;
+      S.rule[b] = a > 0.0 ? 0 : 1;   // a zero right-hand side is solved by x = 0
       S.iters[b] = 0;
       S.alpha[b] = 0.0;
       S.beta[b] = 0.0;
@@ -980,7 +982,10 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
       if (S.active[b]) {
         S.iters[b] += 1;
         S.rr[b] = a;
-        if (a <= S.tol2[b]) S.active[b] = 0;
+        if (a <= S.tol2[b]) {
+          S.active[b] = 0;
+          S.rule[b] = 1;
+        }
       }
       break;
     case S_BETA:  // a = r.z (new)
@@ -998,8 +1003,10 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
         // more than that to get here is telling that this constant is small (skewed lattices with pinned interior
         // nodes: 12 and 35 iterations, error 8e-11 at an estimate of 1e-11).
         if (S.tol_e2 > 0.0 && a > 0.0 && S.energy[b] > 0.0 && e2 <= S.tol_e2 * S.energy[b] &&
-            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b] && S.iters[b] <= 10)
+            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b] && S.iters[b] <= 10) {
           S.active[b] = 0;
+          S.rule[b] = 2;
+        }
       } else {
         S.beta[b] = 0.0;
       }
@@ -1502,7 +1509,8 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
                                         const double* b, double* x, int Bp, double tol, double tol_energy, int max_iter,
                                         int nu, int n_coarse, const double* omegas_host, int precond_fp32, double* work,
-                                        double* relres, double* err_est, int* iters, int* status_host, void* stream) {
+                                        double* relres, double* err_est, int* iters, int* stop_rule, int* status_host,
+                                        void* stream) {
   if (!b || !x || !work || !relres || !iters || !status_host || max_iter < 0) return DIFFHE_E_BADARG;
   Hier H;
   int rc = fill_hier(H, levels, n_levels, Bv, Bp, scale, omegas_host, nu, n_coarse);
@@ -1543,6 +1551,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.energy = sc + 12 * Bp;
   S.est = err_est ? err_est : sc + 13 * Bp;
   S.rr = sc + 14 * Bp;
+  S.rule = stop_rule ? stop_rule : (int*)(sc + 7 * Bp);
   double* alpha_ring = sc + 16 * Bp;              // n_slots (<= 6) rows of Bp step lengths
   double* const alpha_single = S.alpha;
   // tol_energy is asked of the FINAL iterate, which receives one more multigrid correction after the decision
@@ -1592,6 +1601,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     SCALAR(S_RELRES, partA, nbr);
     rc = diffhe::check(hipMemsetAsync(S.est, 0, sizeof(double) * Bp, st));
     if (rc) return rc;
+    if (stop_rule) {  // direct solve: nothing iterated, nothing stopped
+      rc = diffhe::check(hipMemsetAsync(stop_rule, 0, sizeof(int) * Bp, st));
+      if (rc) return rc;
+    }
     rc = diffhe::check_launch();
     if (rc) return rc;
     status_host[0] = 0;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdiffhe_hip.so"))
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
-ABI_VERSION = 5     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
+ABI_VERSION = 6     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
 
 
 class MgLevel(C.Structure):
@@ -57,7 +57,7 @@ SIGNATURES = {
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pcg_workspace_doubles": (_L, [_LV, _I, _I]),
     "diffhe_lattice_pcg_solve": (_I, [_LV, _I, _I, _P, _P, _P, _I, _D, _D, _I, _I, _I, C.POINTER(_D), _I, _P, _P,
-                                      _P, _P, _P, _P]),
+                                      _P, _P, _P, _P, _P]),
     "diffhe_lattice_pcg_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_lattice_kernel_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_lattice_blocks": (_I, [_I, _I]),
@@ -69,6 +69,7 @@ SIGNATURES = {
     "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "diffhe_p1_grad_kappa_shared": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "diffhe_to_node_major": (_I, [_P, _L, _P, _P, _I, _I, _I, _P]),
     "diffhe_to_sample_major": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
 }

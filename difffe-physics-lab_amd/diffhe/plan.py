@@ -14,12 +14,57 @@ mesh.py:127-129 (`free_nodes`) and the index arithmetic implicit in the dense
 """
 from __future__ import annotations
 
+import collections
+import hashlib
+import os
+import shutil
+import threading
 from typing import Optional
 
 import numpy as np
 import torch
 
 from . import _hip
+
+
+_TLS = threading.local()
+
+
+def status_buffer() -> torch.Tensor:
+    """Pinned 4-int host buffer the solve entry points report through (iterations, unconverged count, ...).
+    One per calling THREAD: a forward on the main thread and the backward of another solve on autograd's thread
+    never share it (the library reads/writes it while the GIL is released inside ctypes)."""
+    buf = getattr(_TLS, "status", None)
+    if buf is None:
+        buf = _TLS.status = torch.zeros(4, dtype=torch.int32).pin_memory()
+    return buf
+
+
+def host_arrays(tag: str, build):
+    """`build()` -> dict of numpy arrays, through an optional on-disk cache shared by the ranks of a node.
+
+    With DIFFHE_PLAN_CACHE=<dir> set, the first process to need `tag` builds it and publishes one .npy per array
+    (written under a private name, then renamed: readers never see a partial entry); every other process maps the
+    files instead of repeating the numpy work (the fine-level gather lists and reference-order integrals of a
+    1024^2 lattice are ~5 s of host time per rank -- eight ranks starting together would each pay it).  Unset: no
+    cache, `build()` runs."""
+    root = os.environ.get("DIFFHE_PLAN_CACHE")
+    if not root:
+        return build()
+    path = os.path.join(root, tag)
+    if not os.path.isdir(path):
+        arrays = build()
+        tmp = f"{path}.tmp{os.getpid()}.{threading.get_ident()}"
+        os.makedirs(tmp, exist_ok=True)
+        for name, a in arrays.items():
+            np.save(os.path.join(tmp, name + ".npy"), np.asarray(a))
+        try:
+            os.rename(tmp, path)
+        except OSError:                      # another rank published the same entry first
+            shutil.rmtree(tmp, ignore_errors=True)
+        return arrays
+    return {fn[:-4]: np.load(os.path.join(path, fn), mmap_mode="r") for fn in sorted(os.listdir(path))
+            if fn.endswith(".npy")}
 
 
 def padded_batch(B: int) -> int:
@@ -71,6 +116,7 @@ def build_ell_pattern(elements: np.ndarray, n: int):
     point at the row itself and carry no contribution.
     """
     m, npe = elements.shape
+    _check_gather_code_range(m)
     nloc = npe * npe
     e_idx = np.repeat(np.arange(m, dtype=np.int64), nloc)
     pq = np.tile(np.arange(nloc, dtype=np.int64), m)
@@ -106,10 +152,17 @@ def build_ell_pattern(elements: np.ndarray, n: int):
     ent_ptr = np.zeros(W * n + 1, dtype=np.int64)
     np.cumsum(counts, out=ent_ptr[1:])
     slot_of = (contrib_entry // n).reshape(m, nloc).T.copy().astype(np.int32)
-    if ent_ptr[-1] >= 2 ** 31 or m >= 2 ** 25:
+    if ent_ptr[-1] >= 2 ** 31:
         raise ValueError("mesh too large for int32 gather lists")
     return dict(W=W, cols=ell_cols.reshape(W, n), ent_ptr=ent_ptr.astype(np.int32), contrib=contrib,
                 slot_of=slot_of)
+
+
+def _check_gather_code_range(m: int) -> None:
+    """Gather codes are e * 64 + pq in an int32 (assemble_rows_kernel decodes e = code >> 6): 2^25 elements at most
+    (a 4096 x 4096 lattice).  Beyond that the cast would wrap silently and the kernel would read out of bounds."""
+    if m >= 2 ** 25:
+        raise ValueError(f"mesh too large for int32 gather lists: {m} elements >= 2**25")
 
 
 def detect_lattice(elements: np.ndarray, n: int):
@@ -146,6 +199,7 @@ def build_dia_pattern(nx: int, ny: int):
     of an entry are listed in ELEMENT ORDER (then local-entry order): the order the reference's loop adds them.
     Returns dict(We=7, cols (7,n) i32, ent_ptr (7n+1) i32, contrib i32 packed e * 64 + p * 3 + q)."""
     n, W = (nx + 1) * (ny + 1), nx + 1
+    _check_gather_code_range(2 * nx * ny)
     r, c = np.divmod(np.arange(n, dtype=np.int64), W)
     up, dn, lf, rt = r < ny, r >= 1, c >= 1, c < nx          # a quad exists above / below / left / right of the node
     q = lambda rr, cc: rr * nx + cc                         # noqa: E731  quad index
@@ -182,6 +236,7 @@ def build_dia_pattern(nx: int, ny: int):
 def _build_dia_pattern_sorted(nx: int, ny: int):
     """The same lists from a stable sort over all 9 m local entries (the definition; kept as the test's yardstick)."""
     n, W = (nx + 1) * (ny + 1), nx + 1
+    _check_gather_code_range(2 * nx * ny)
     el = lattice_elements(nx, ny)
     m = len(el)
     e_idx = np.repeat(np.arange(m, dtype=np.int64), 9)
@@ -298,7 +353,7 @@ class LatticeLevel:
         self.coords = dev(nodes2d.reshape(self.n, 2).T)
         self.elems = dev(lattice_elements(nx, ny).T.astype(np.int32))
         self.is_bc = dev(is_bc2d.reshape(self.n).astype(np.uint8))
-        pat = build_dia_pattern(nx, ny)
+        pat = host_arrays(f"dia_{nx}x{ny}", lambda: build_dia_pattern(nx, ny))
         self.cols, self.ent_ptr, self.contrib = dev(pat["cols"]), dev(pat["ent_ptr"]), dev(pat["contrib"])
         self.k0 = torch.empty((9, self.m), dtype=torch.float64, device=device)
         m0 = torch.empty((9, self.m), dtype=torch.float64, device=device)
@@ -306,9 +361,10 @@ class LatticeLevel:
                                                  _hip.ptr(self.k0), _hip.ptr(m0), _stream(device)),
                    "diffhe_p1_element_integrals")
         self._m0 = m0 if with_load_matrix else None
-        tn, dn = reference_order_integrals(np.ascontiguousarray(nodes2d.reshape(self.n, 2).T),
-                                           lattice_elements(nx, ny).T)
-        self.tnum, self.den = dev(tn), dev(dn)       # reference-order assembly (fine level; kappa folded in)
+        flat = np.ascontiguousarray(nodes2d.reshape(self.n, 2).T)
+        ref = host_arrays(f"refint_{nx}x{ny}_{hashlib.blake2b(flat.tobytes(), digest_size=8).hexdigest()}",
+                          lambda: dict(zip(("tn", "dn"), reference_order_integrals(flat, lattice_elements(nx, ny).T))))
+        self.tnum, self.den = dev(ref["tn"]), dev(ref["dn"])   # reference-order assembly (fine level; kappa folded in)
         # quad-diagonal coupling b-d: local (1,2) of [a,b,d], local (0,2) of [b,c,d]; exactly 0 for
         # right triangles -> 3 stored diagonals instead of 4
         hyp = max(float(self.k0[5, 0::2].abs().max()), float(self.k0[2, 1::2].abs().max()))
@@ -365,10 +421,17 @@ class SolvePlan:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
         self.is_bc = dev(is_bc)
         self.g = dev(g)
+        self.has_dirichlet_data = bool(np.any(g != 0.0))     # some g_i != 0: u = x + g needs its own buffer
+        self._bc_index = None
         self.coords = dev(nodes.T)                                   # (dim, n) SoA
         self.elems = dev(elements.T.astype(np.int32))                # (npe, m) SoA
-        self.pinned_status = torch.zeros(4, dtype=torch.int32).pin_memory()
-        self.warm = {}     # ("u" | "lambda", Bp) -> previous (n, Bp) solution, for DifferentiableFESolver(warm_start=True)
+        # warm-start vectors of DifferentiableFESolver(warm_start=...): (kind, Bp, kappa layout, reaction) -> previous
+        # (n, Bp) solution.  Kept on the PLAN so that a loop that builds a new solver per step (the reference's pattern)
+        # still benefits; keyed by what makes two solves comparable, so solvers with another kappa layout or reaction
+        # term never feed each other's guesses; at most `_WARM_MAX` vectors live (least recently used goes first).
+        self.warm = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self._build_lock = threading.RLock()     # lazily built parts (ELL pattern, AMG hierarchy): one builder at a time
 
         self._nodes_host = nodes
         self._lumped_mass = None
@@ -377,6 +440,7 @@ class SolvePlan:
         self._ell_ready = False
         self.levels = []
         self.n_bc_interior = 0
+        self.closed_boundary = False
         # --- 1D chain fast path ---------------------------------------------------------
         self.is_lattice = False
         self.is_chain = bool(self.dim == 1 and self.n == self.m + 1
@@ -401,6 +465,9 @@ class SolvePlan:
             # coarse nodes, so many of them (pinned regions, holes) weaken the V-cycle -- the solver then routes
             # the mesh to the aggregation-multigrid path, whose Galerkin operators see every one of them
             self.n_bc_interior = int(bc2d[1:-1, 1:-1].sum())
+            # every node of the four edges is a Dirichlet node (what FEMesh.rectangle produces): the regime in which
+            # the energy norm controls nodal values and a scalar kappa per sample may stay factored
+            self.closed_boundary = bool(bc2d[0, :].all() and bc2d[-1, :].all() and bc2d[:, 0].all() and bc2d[:, -1].all())
             while len(self.levels) < 16:
                 self.levels.append(LatticeLevel(nodes2d, bc2d, device, with_load_matrix=not self.levels))
                 step = coarsening_step(nodes2d)
@@ -411,7 +478,29 @@ class SolvePlan:
         # --- general ELL path: built eagerly for general meshes, lazily for lattice meshes (only
         # method="ell" needs it there; the pattern build costs ~20 s of numpy at 1024^2) ------------
         if not self.is_lattice:
-            self.ensure_ell()
+            self._ensure_ell()
+
+    def bc_index(self) -> torch.Tensor:
+        """Device int64 indices of the Dirichlet nodes."""
+        if self._bc_index is None:
+            self._bc_index = torch.nonzero(self.is_bc).reshape(-1)
+        return self._bc_index
+
+    _WARM_MAX = 4
+
+    def warm_get(self, key):
+        with self._lock:
+            x = self.warm.get(key)
+            if x is not None:
+                self.warm.move_to_end(key)
+            return x
+
+    def warm_put(self, key, x):
+        with self._lock:
+            self.warm[key] = x
+            self.warm.move_to_end(key)
+            while len(self.warm) > self._WARM_MAX:
+                self.warm.popitem(last=False)
 
     def dense_level(self, max_nodes: int = 1200):
         """Index of the first level with at most `max_nodes` nodes (33 x 33 for power-of-two meshes), or None: the
@@ -424,6 +513,11 @@ class SolvePlan:
         the host -- identity rows stay identity -- and uploaded in the V-cycle's storage type (fp64 for idx 0)."""
         key = (idx, bool(fp32))
         cache = self.__dict__.setdefault("_dense_cache", {})
+        with self._lock:
+            self._dense_coarse_build(cache, key, idx, vals, fp32)
+        return idx, cache[key]
+
+    def _dense_coarse_build(self, cache, key, idx, vals, fp32):
         if key not in cache:
             lev = self.levels[idx]
             d = vals[idx].detach().to("cpu", torch.float64).numpy().reshape(lev.nd, lev.n)
@@ -438,7 +532,6 @@ class SolvePlan:
             inv = np.linalg.inv(K)
             inv = 0.5 * (inv + inv.T)                        # symmetric to the last bit: the cycle stays symmetric
             cache[key] = torch.from_numpy(inv.astype(np.float32) if fp32 else inv).to(self.device).contiguous()
-        return idx, cache[key]
 
     def lumped_mass(self) -> torch.Tensor:
         """(n,) lumped P1 mass m_i = sum over the elements at node i of |e| / (dim + 1): the row sums of the load
@@ -449,6 +542,10 @@ class SolvePlan:
 
     def ensure_ell(self):
         """ELL pattern, gather lists, element integrals and the ELL load matrix of the general path."""
+        with self._build_lock:
+            self._ensure_ell()
+
+    def _ensure_ell(self):
         if self._ell_ready:
             return
         L = _hip.lib()
@@ -484,10 +581,14 @@ class SolvePlan:
 
     def ensure_amg(self):
         """Aggregation hierarchy of the general path (diffhe/amg.py), uploaded once per mesh."""
+        with self._build_lock:
+            self._ensure_amg()
+
+    def _ensure_amg(self):
         if getattr(self, "amg_levels", None) is not None:
             return
         from .amg import build_hierarchy
-        self.ensure_ell()
+        self._ensure_ell()
         device = self.device
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
         host = build_hierarchy(self.cols.cpu().numpy(), self.is_bc.cpu().numpy())
@@ -506,13 +607,18 @@ def _fingerprint(mesh):
             hash(tuple(bc.items())) if len(bc) <= 1 << 16 else (hash(tuple(bc.keys())), hash(tuple(bc.values()))))
 
 
+_PLAN_LOCK = threading.Lock()
+
+
 def get_plan(mesh, device: torch.device) -> SolvePlan:
-    """Cached plan for (mesh, device); rebuilt when nodes/elements/BCs change."""
-    cache = mesh.__dict__.setdefault("_diffhe_plans", {})
+    """Cached plan for (mesh, device); rebuilt when nodes/elements/BCs change.  One builder at a time: two threads
+    that meet on a new mesh get the same plan."""
     key = (str(device), _fingerprint(mesh))
-    plan: Optional[SolvePlan] = cache.get(key)
-    if plan is None:
-        cache.clear()
-        plan = SolvePlan(mesh, device)
-        cache[key] = plan
+    with _PLAN_LOCK:
+        cache = mesh.__dict__.setdefault("_diffhe_plans", {})
+        plan: Optional[SolvePlan] = cache.get(key)
+        if plan is None:
+            cache.clear()
+            plan = SolvePlan(mesh, device)
+            cache[key] = plan
     return plan

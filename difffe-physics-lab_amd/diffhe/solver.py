@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import _hip
 from .mesh import FEMesh
-from .plan import SolvePlan, get_plan, padded_batch, _stream
+from .plan import SolvePlan, get_plan, padded_batch, status_buffer, _stream
 
 # kappa layouts
 K_SCALAR, K_SAMPLE, K_ELEM, K_SAMPLE_ELEM = 0, 1, 2, 3
@@ -47,6 +47,11 @@ class SolveInfo:
     adj_max_relres: float = 0.0
     err_est: float = 0.0        # lattice path: max over samples of the estimated relative energy-norm error
     adj_err_est: float = 0.0
+    # lattice path: how many samples each rule stopped, forward / adjoint: {"residual": ., "energy": ., "cap": .}
+    # ("cap" = neither rule fired before the iteration cap; the direct dense path iterates nothing and reports {})
+    stop_rules: Optional[dict] = None
+    adj_stop_rules: Optional[dict] = None
+    tol_energy: float = 0.0     # the energy-norm tolerance in force for this call (0: residual rule alone)
 
 
 def _resolve_device(device) -> torch.device:
@@ -151,13 +156,14 @@ class _Engine:
     def reaction_shifts(self, c, n_levels):
         """Per-level (n,) diagonal shifts c * M_L (0 on Dirichlet rows) of a FACTORED lattice operator, cached on the plan."""
         p = self.p
-        cache = p.__dict__.setdefault("_shift_cache", {})
-        if cache.get("c") != c:
-            cache.clear()
-            cache["c"] = c
-            cache["levels"] = [c * torch.where(lev.is_bc.bool(), torch.zeros_like(lev.lumped_mass()), lev.lumped_mass())
-                               for lev in p.levels]
-        return cache["levels"][:n_levels]
+        with p._lock:       # solvers with different c may share the plan (and run on different threads)
+            cache = p.__dict__.setdefault("_shift_cache", {})
+            if c not in cache:
+                while len(cache) >= 4:
+                    cache.pop(next(iter(cache)))
+                cache[c] = [c * torch.where(lev.is_bc.bool(), torch.zeros_like(lev.lumped_mass()), lev.lumped_mass())
+                            for lev in p.levels]
+            return cache[c][:n_levels]
 
     def add_reaction(self, vals, c, lattice):
         """A += c M_L on the free rows (M_L = lumped mass, diagonal): the stored main diagonal is slot 0 of both
@@ -205,11 +211,11 @@ class _Engine:
         work = torch.empty(L.diffhe_cg_workspace_doubles(p.n, Bp), dtype=torch.float64, device=p.device)
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
         iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        st = status_buffer()
         _hip.check(L.diffhe_ell_cg_solve(_hip.ptr(vals), _hip.ptr(p.cols), _hip.ptr(rhs), _hip.ptr(x), p.n, p.W, Bp,
                                          Bv, self.tol, self.max_iter, self.check_every, _hip.ptr(work),
-                                         _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(p.pinned_status),
+                                         _hip.ptr(relres), _hip.ptr(iters), _hip.ptr(st),
                                          _stream(p.device)), "diffhe_ell_cg_solve")
-        st = p.pinned_status
         return x, int(st[0]), int(st[1]), relres
 
     # -- lattice path -----------------------------------------------------------------------
@@ -304,6 +310,8 @@ class _Engine:
         # a multigrid-preconditioned CG that has not converged in a few hundred iterations never will:
         # bound the loop so a defect surfaces as `not_converged` instead of minutes of GPU time
         est = torch.empty(Bp, dtype=torch.float64, device=p.device)
+        rule = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        st = status_buffer()
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               float(mg.get("tol_energy", 0.0) or 0.0),
                                               min(self.max_iter, 500), len(omegas), mg["n_coarse"], om,
@@ -311,10 +319,10 @@ class _Engine:
                                               | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
                                               | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0),
                                               _hip.ptr(work),
-                                              _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters),
-                                              _hip.ptr(p.pinned_status), _stream(p.device)), "diffhe_lattice_pcg_solve")
-        st = p.pinned_status
+                                              _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters), _hip.ptr(rule),
+                                              _hip.ptr(st), _stream(p.device)), "diffhe_lattice_pcg_solve")
         self.last_est = est
+        self.last_rule = rule
         return x, int(st[0]), int(st[1]), relres
 
     # -- general path with the aggregation-multigrid preconditioner ---------------------------------
@@ -350,6 +358,7 @@ class _Engine:
         work = torch.empty(L.diffhe_ell_amg_workspace_doubles(arr, nl, Bp), dtype=torch.float64, device=p.device)
         relres = torch.empty(Bp, dtype=torch.float64, device=p.device)
         iters = torch.empty(Bp, dtype=torch.int32, device=p.device)
+        st = status_buffer()
         _hip.check(L.diffhe_ell_amg_pcg_solve(arr, nl, Bv, _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               min(self.max_iter, int(opts.get("max_iter", 20000))), int(opts["n_coarse"]),
                                               int(opts["gamma"]),
@@ -357,8 +366,7 @@ class _Engine:
                                               int(opts.get("fp32", 0)) | ((0 if int(opts.get("floor", 1)) else 1) << 4),
                                               _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(iters),
-                                              _hip.ptr(p.pinned_status), _stream(p.device)), "diffhe_ell_amg_pcg_solve")
-        st = p.pinned_status
+                                              _hip.ptr(st), _stream(p.device)), "diffhe_ell_amg_pcg_solve")
         return x, int(st[0]), int(st[1]), relres
 
     def grad_kappa_factored(self, vals, lift, lam, x, Bp):
@@ -387,11 +395,30 @@ class _Engine:
                                           _stream(p.device)), "diffhe_p1_grad_kappa")
         return dk_e, dk_sum
 
+    def grad_kappa_shared(self, lam, x, B, Bp):
+        """dL/dkappa_e summed over the batch, (m,): the gradient of ONE per-element field shared by all samples,
+        without the (m, Bp) per-sample gradient (what the multi-GPU gradient all-reduce carries)."""
+        p, L = self.p, self.L
+        dk = torch.empty(p.m, dtype=torch.float64, device=p.device)
+        k0 = p.k0 if p._ell_ready else p.levels[0].k0
+        _hip.check(L.diffhe_p1_grad_kappa_shared(_hip.ptr(p.elems), _hip.ptr(k0), _hip.ptr(lam), _hip.ptr(x),
+                                                 _hip.ptr(p.g), p.npe, p.m, B, Bp, _hip.ptr(dk), _stream(p.device)),
+                   "diffhe_p1_grad_kappa_shared")
+        return dk
 
-def _solve_forward(solver, kappa, f, load=None):
+
+def _rule_counts(rule: torch.Tensor, B: int) -> dict:
+    c = torch.bincount(rule[:B].to(torch.int64), minlength=3).tolist()
+    return {"cap": c[0], "residual": c[1], "energy": c[2]}
+
+
+def _solve_forward(solver, kappa, f, load=None, node_major=False):
     """u = (K(kappa) + c M_L)^{-1} (F(f) + load) with Dirichlet elimination (c = solver.reaction, 0 for the reference's
     problem).  Returns (u, state); `state` carries what the explicit adjoint needs (assembled operators, the
-    eliminated solution, layout facts)."""
+    eliminated solution, layout facts).
+    node_major (2D paths): f, load and u are (n, B) -- the solver's own layout -- instead of the API's (B, n): no
+    layout change on the way in or out (with B a valid padded batch and zero Dirichlet data, u IS the solver's
+    iterate, no copy at all)."""
     ctx = types.SimpleNamespace()
     reaction = float(solver.reaction)
     if load is not None and load.numel() == 0:
@@ -401,6 +428,12 @@ def _solve_forward(solver, kappa, f, load=None):
     out_device = f.device
     batched = f.dim() == 2
     m, n = plan.m, plan.n
+    if node_major and (plan.is_chain or not batched):
+        raise ValueError("layout='node' takes (n, B) tensors on 2D meshes")
+    if node_major:
+        f = f.t()                       # a (B, n) VIEW for the shape logic below; the data stays (n, B)
+        load = load.t() if load is not None else None
+    ctx.node_major = node_major
     B_f = f.shape[0] if batched else None
     mode, B_k = _kappa_mode(kappa, m, B_f)
     B = B_f if B_f is not None else (B_k if B_k is not None else 1)
@@ -425,7 +458,7 @@ def _solve_forward(solver, kappa, f, load=None):
         # conditioned for their size and multigrid keeps error ~ residual: 1e-12 (validated against the oracle
         # in every bench run).  Per-element fields (their per-element gradients amplify solver error), partly
         # Neumann boundaries and the general path get one or two more decades.
-        closed = lattice and plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
+        closed = lattice and plan.closed_boundary
         simple = mode in (K_SCALAR, K_SAMPLE)
         # small systems (< 10^5 nodes) get one more decade whatever their kind: there an iteration costs next to
         # nothing, and odd shapes (7 x 61 cells of aspect 50, say) converge slowly enough for the error to sit well
@@ -436,8 +469,12 @@ def _solve_forward(solver, kappa, f, load=None):
     # near-null mode).  With large Neumann parts the nearly constant mode carries next to no energy per unit of
     # amplitude, and the estimate fell 40x below the nodal error (330 x 125 lattice, Dirichlet data on one edge and
     # one interior node: 4e-10 in u at an estimate of 1e-11) -- such meshes stop on the residual alone, as before.
-    closed_lattice = lattice and plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
+    closed_lattice = lattice and plan.closed_boundary
     if not closed_lattice and "tol_energy" not in solver._mg_user:
+        mg["tol_energy"] = 0.0
+    # an explicit `tol` is a request on the RESIDUAL: the energy-norm stop (which ends a solve at relative residuals
+    # up to ~3e-7) steps aside unless the caller asked for it too
+    if solver._tol_user is not None and "tol_energy" not in solver._mg_user:
         mg["tol_energy"] = 0.0
     if "tol_energy" not in solver._mg_user and mg.get("tol_energy"):
         # The energy-norm stop is calibrated on NODAL error (the estimate sits 3-10x above it).  Per-element
@@ -450,7 +487,8 @@ def _solve_forward(solver, kappa, f, load=None):
             mg["tol_energy"] *= 0.1
     solver.tol = eng.tol = tol          # `solver.tol` reports the tolerance of the last call
     ctx.mg, ctx.amg = mg, amg
-    f_dev = f.detach().to(plan.device, torch.float64).contiguous()
+    f_dev = f.detach().to(plan.device, torch.float64)
+    f_dev = f_dev if node_major else f_dev.contiguous()      # node-major: a transposed view of contiguous (n, B) data
     info = SolveInfo()
     ctx.solver, ctx.plan, ctx.eng = solver, plan, eng
     ctx.mode, ctx.B, ctx.batched_f, ctx.out_device = mode, B, batched, out_device
@@ -460,11 +498,17 @@ def _solve_forward(solver, kappa, f, load=None):
     load_dev = None
     if load is not None:      # extra nodal load, added to the assembled F on the free rows
         load_dev = load.detach().to(plan.device, torch.float64)
-        load_dev = (load_dev.reshape(1, n).expand(B, n) if load_dev.dim() == 1 else load_dev).contiguous()
+        load_dev = (load_dev.reshape(1, n).expand(B, n) if load_dev.dim() == 1 else load_dev).contiguous()   # (B, n)
         if load_dev.shape != (B, n):
             raise ValueError(f"load must be (n,) or (B,n) with B={B}, n={n}, got {tuple(load.shape)}")
     ctx.load_batched = load is not None and load.dim() == 2
     ctx.reaction = reaction
+    if plan.n_bc == 0 and reaction == 0.0:
+        # no Dirichlet node and no reaction term: K is singular (constants are in its null space).  The reference
+        # solves it anyway and returns garbage of size 1e15 (solver.py:174, no check); here the 1D scan returns NaN
+        # and the iterative paths stop at the iteration cap -- either way it is said out loud
+        warnings.warn("diffhe: the system is singular (pure Neumann problem: no Dirichlet node, no reaction term); "
+                      "the returned values are not a solution", RuntimeWarning)
     # the scan solver inverts a pure path-graph Laplacian: with a reaction term the chain takes the general path
     if reaction and plan.is_p2:
         raise NotImplementedError("reaction term with P2 elements: the lumped P2 mass vanishes at the vertices")
@@ -497,7 +541,7 @@ def _solve_forward(solver, kappa, f, load=None):
         # per-sample scalar kappa stays factored on closed lattices only: with large Neumann parts the system is
         # ill-conditioned enough (cond ~ 1e7 in the randomised sweep) for the last-bit difference between
         # kappa_b (K_1 x) and (sum_e kappa_b k0_e) x to show as 4e-10 in u
-        closed_ = plan.n_bc >= 2 * (plan.levels[0].nx + plan.levels[0].ny)
+        closed_ = plan.closed_boundary
         # factored operator (one plan-constant unit matrix per level, scalar kappa per sample or for all): the levels
         # from ~33^2 nodes down are replaced by ONE dense product with the cached inverse of that level's matrix (they
         # cost ~45 launch-bound launches per cycle); a mesh that small as a whole -- the reference's own 2D sizes -- is
@@ -515,7 +559,7 @@ def _solve_forward(solver, kappa, f, load=None):
             shift = eng.reaction_shifts(reaction, len(vals))
         elif reaction:
             eng.add_reaction(vals, reaction, lattice=True)
-        f_nm = eng.to_node_major(f_dev, B, Bp, n)
+        f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
         if load_dev is not None:
             rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
@@ -527,17 +571,20 @@ def _solve_forward(solver, kappa, f, load=None):
                 info.path = "lattice-direct"
                 mg = ctx.mg = dict(mg, fp32=0)        # the direct product runs in fp64
             dense = plan.dense_coarse(didx, vals, bool(mg.get("fp32")))
+        wkey = (Bp, mode, reaction)
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense,
-                                              x0=plan.warm.get(("u", Bp)) if solver.warm_start else None, shift=shift)
-        ctx.shift = shift
+                                              x0=plan.warm_get(("u",) + wkey) if solver.warm_start else None, shift=shift)
+        ctx.shift, ctx.wkey = shift, wkey
         if solver.warm_start and not bad:
-            plan.warm[("u", Bp)] = x                  # never written again: the next solve starts from a copy
+            plan.warm_put(("u",) + wkey, x)           # never written again: the next solve starts from a copy
+        info.stop_rules = _rule_counts(eng.last_rule, B) if info.path != "lattice-direct" else {}
+        info.tol_energy = float(mg.get("tol_energy", 0.0) or 0.0)
         ctx.dense = dense
         ctx.factored = factored
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
         info.err_est = float(eng.last_est[:B].max())
-        u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+        u = _from_node_major(eng, x, B, Bp, n, node_major)
         ctx.saved = (vals, x, Bp, Bv, scale)
         ctx.vals32 = vals32
         ctx.lift = lift if Bv == 1 else None
@@ -548,7 +595,7 @@ def _solve_forward(solver, kappa, f, load=None):
         vals, lift = eng.assemble(kdev, kse, ksb, Bv)
         if reaction:
             eng.add_reaction([vals], reaction, lattice=False)
-        f_nm = eng.to_node_major(f_dev, B, Bp, n)
+        f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
         rhs = eng.load_vector(f_nm, lift, Bv, Bp)
         if load_dev is not None:
             rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
@@ -565,15 +612,37 @@ def _solve_forward(solver, kappa, f, load=None):
             x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
-        u = eng.to_sample_major(x, B, Bp, n, add=plan.g)
+        u = _from_node_major(eng, x, B, Bp, n, node_major)
         ctx.saved = (vals, x, Bp, Bv, None)
     solver.last_info = info
     ctx.path = info.path
     if info.not_converged:
         warnings.warn(f"diffhe: {info.not_converged} of {B} systems did not reach tol={solver.tol:g} "
                       f"(max relative residual {info.max_relres:.2e}, path {info.path})", RuntimeWarning)
-    out = u if batched or B > 1 else u[0]
+    out = u if batched or B > 1 or node_major else u[0]
     return out.to(out_device), ctx
+
+
+def _as_node_major(eng, f_dev, B, Bp, n, node_major):
+    """The (n, Bp) forcing the kernels read.  API layout: one transposing pass.  Node-major input ((B, n) view of
+    contiguous (n, B) data): used as it is when B needs no padding, else copied into the padded buffer."""
+    if not node_major:
+        return eng.to_node_major(f_dev, B, Bp, n)
+    f_nb = f_dev.t()
+    if Bp == B and f_nb.is_contiguous():
+        return f_nb
+    out = torch.zeros((n, Bp), dtype=torch.float64, device=f_dev.device)
+    out[:, :B] = f_nb
+    return out
+
+
+def _from_node_major(eng, x, B, Bp, n, node_major):
+    """u in the caller's layout from the eliminated-system solution x (n, Bp), Dirichlet values added."""
+    p = eng.p
+    if not node_major:
+        return eng.to_sample_major(x, B, Bp, n, add=p.g)
+    xo = x if Bp == B else x[:, :B]
+    return xo + p.g.unsqueeze(1) if p.has_dirichlet_data else xo   # zero Dirichlet data: u IS x, nothing is copied
 
 
 def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
@@ -582,9 +651,14 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
     Returns (grad_kappa | None, grad_f | None, grad_load | None)."""
     plan, eng, mode, B = ctx.plan, ctx.eng, ctx.mode, ctx.B
     m, n = plan.m, plan.n
-    g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
+    node_major = getattr(ctx, "node_major", False)
+    if node_major:
+        g_dev = gbar.detach().to(plan.device, torch.float64).reshape(n, B)
+    else:
+        g_dev = gbar.detach().to(plan.device, torch.float64).reshape(B, n).contiguous()
     info = ctx.solver.last_info
     grad_load = None
+    dk_shared = None
     if ctx.path.startswith("chain1d"):
         need_f_user, need_f = need_f, need_f or need_load    # the chain's extra load went in as forcing
         kdev, ksb, kse, u = ctx.saved
@@ -607,13 +681,27 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         need_f = need_f_user
     else:
         vals, x, Bp, Bv, scale = ctx.saved
-        rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
+        if node_major:
+            # the adjoint right-hand side must vanish on Dirichlet rows (lambda_bc = 0): a cotangent that already does
+            # (L = sum u^2 with zero Dirichlet data) is used as it is
+            dirty = plan.n_bc > 0 and bool((g_dev[plan.bc_index()] != 0).any())
+            if Bp == B and g_dev.is_contiguous() and not dirty:
+                rhs = g_dev
+            else:
+                rhs = torch.zeros((n, Bp), dtype=torch.float64, device=plan.device)
+                rhs[:, :B] = g_dev
+                if dirty:
+                    rhs[plan.bc_index()] = 0.0
+        else:
+            rhs = eng.to_node_major(g_dev, B, Bp, n, zero_mask=plan.is_bc)
         if ctx.path in ("lattice-mgpcg", "lattice-direct"):
             ws = ctx.solver.warm_start is True
             lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense,
-                                                    x0=plan.warm.get(("lambda", Bp)) if ws else None, shift=ctx.shift)
+                                                    x0=plan.warm_get(("lambda",) + ctx.wkey) if ws else None,
+                                                    shift=ctx.shift)
             if ws and not bad:
-                plan.warm[("lambda", Bp)] = lam
+                plan.warm_put(("lambda",) + ctx.wkey, lam)
+            info.adj_stop_rules = _rule_counts(eng.last_rule, B) if ctx.path != "lattice-direct" else {}
             info.adj_err_est = float(eng.last_est[:B].max())
         elif ctx.path == "ell-amgpcg":    # same preconditioner (and the saved per-sample coarse operators) as forward
             lam, its, bad, relres = eng.amg_pcg(ctx.amg_hier, rhs, Bp, Bv, ctx.amg)
@@ -630,16 +718,20 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
             dk_sum = eng.grad_kappa_factored(vals, ctx.lift, lam, x, Bp)   # shared matrix: one strip pass
             if dk_sum is not None and mode == K_SCALAR and not ctx.factored:
                 dk_sum = dk_sum / ctx.kappa_value                           # vals carry kappa: K = kappa K_1
-        if need_k and dk_sum is None:
+        if need_k and mode == K_ELEM:
+            dk_shared = eng.grad_kappa_shared(lam, x, B, Bp)       # (m,): summed over the batch in the kernel
+        elif need_k and dk_sum is None:
             dk_nm, dk_sum = eng.grad_kappa(lam, x, Bp, want_e)
-        dk_sample = dk_sum[:B] if need_k else None
+        dk_sample = dk_sum[:B] if need_k and dk_sum is not None else None
         dk_elem = None
-        if need_k and want_e:
+        if need_k and mode == K_SAMPLE_ELEM:
             dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
-        df = eng.to_sample_major(eng.apply_M(lam, Bp, lattice=ctx.path.startswith("lattice-")), B, Bp, n) \
-            if need_f else None
+        df = None
+        if need_f:
+            df = eng.apply_M(lam, Bp, lattice=ctx.path.startswith("lattice-"))
+            df = df[:, :B] if node_major else eng.to_sample_major(df, B, Bp, n)
         if need_load:
-            grad_load = eng.to_sample_major(lam, B, Bp, n)
+            grad_load = lam[:, :B].clone() if node_major else eng.to_sample_major(lam, B, Bp, n)
 
     grad_k = None
     if need_k:
@@ -648,7 +740,7 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         elif mode == K_SAMPLE:
             grad_k = dk_sample.reshape(ctx.kappa_shape)
         elif mode == K_ELEM:
-            grad_k = dk_elem.sum(dim=0).reshape(ctx.kappa_shape)
+            grad_k = (dk_shared if dk_shared is not None else dk_elem.sum(dim=0)).reshape(ctx.kappa_shape)
         else:
             grad_k = dk_elem.reshape(ctx.kappa_shape)
         grad_k = grad_k.to(ctx.kappa_device)
@@ -657,7 +749,7 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         grad_f = df if ctx.batched_f else df.sum(dim=0)
         grad_f = grad_f.to(ctx.out_device)
     if grad_load is not None:
-        grad_load = (grad_load if ctx.load_batched else grad_load.sum(dim=0)).to(ctx.out_device)
+        grad_load = (grad_load if ctx.load_batched else grad_load.sum(dim=1 if node_major else 0)).to(ctx.out_device)
     return grad_k, grad_f, grad_load
 
 
@@ -686,11 +778,12 @@ class _StateGuard:
 
 @torch.library.custom_op("diffhe::fe_solve", mutates_args=())
 def fe_solve(kappa: torch.Tensor, f: torch.Tensor, load: torch.Tensor, handle: int,
-             save: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+             save: bool, node_major: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(u, token) = solve with the solver registered under `handle`; `token` names the saved
-    adjoint state (0 when `save` is false).  `load`: extra nodal load vector, empty for none."""
+    adjoint state (0 when `save` is false).  `load`: extra nodal load vector, empty for none.
+    node_major: f, load and u are (n, B) instead of (B, n)."""
     solver = _SOLVERS[handle]
-    u, state = _solve_forward(solver, kappa, f, load)
+    u, state = _solve_forward(solver, kappa, f, load, node_major)
     token = 0
     if save:
         token = next(_TOKENS)
@@ -699,9 +792,11 @@ def fe_solve(kappa: torch.Tensor, f: torch.Tensor, load: torch.Tensor, handle: i
 
 
 @fe_solve.register_fake
-def _fe_solve_fake(kappa, f, load, handle, save):
+def _fe_solve_fake(kappa, f, load, handle, save, node_major=False):
     solver = _SOLVERS[handle]
     n, m = solver.mesh.n_nodes, solver.mesh.n_elements
+    if node_major:
+        return f.new_empty(tuple(f.shape), dtype=torch.float64), torch.empty((), dtype=torch.int64)
     B_f = f.shape[0] if f.dim() == 2 else None
     _, B_k = _kappa_mode(kappa, m, B_f)
     B = B_f if B_f is not None else (B_k if B_k is not None else 1)
@@ -730,17 +825,25 @@ def _fe_solve_backward_fake(gbar, token, need_k, need_f, need_load, kappa_like, 
 
 
 def _fe_setup_context(ctx, inputs, output):
-    kappa, f, load, _, _ = inputs
-    ctx.save_for_backward(output[1], kappa, f, load)
+    kappa, f, load, _, _, node_major = inputs
+    # node-major: u may BE the solver's saved iterate -- saving it lets autograd refuse a backward after an in-place edit
+    ctx.save_for_backward(output[1], kappa, f, load, *((output[0],) if node_major else ()))
     if not isinstance(output[1], torch._subclasses.FakeTensor):
         ctx.state_guard = _StateGuard(int(output[1]))       # frees the adjoint state together with the graph
 
 
 def _fe_backward(ctx, grad_u, _grad_token):
-    token, kappa, f, load = ctx.saved_tensors
+    if torch.is_grad_enabled():
+        # backward(create_graph=True) / autograd.grad(..., create_graph=True): the caller wants a gradient it can
+        # differentiate again.  The explicit adjoint below is not recorded by autograd, so what it returns would carry
+        # no graph and a Hessian-vector product taken through it would silently be wrong (zero) -- refuse instead.
+        raise RuntimeError("diffhe: second-order derivatives through DifferentiableFESolver are not implemented "
+                           "(the adjoint solve is explicit and not itself differentiable): backward/grad was called with "
+                           "create_graph=True.  Use first-order gradients, or finite differences of them.")
+    token, kappa, f, load = ctx.saved_tensors[:4]
     need_k, need_f, need_load = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
     gk, gf, gl = torch.ops.diffhe.fe_solve_backward(grad_u, token, need_k, need_f, need_load, kappa, f, load)
-    return (gk if need_k else None), (gf if need_f else None), (gl if need_load else None), None, None
+    return (gk if need_k else None), (gf if need_f else None), (gl if need_load else None), None, None, None
 
 
 torch.library.register_autograd("diffhe::fe_solve", _fe_backward, setup_context=_fe_setup_context)
@@ -846,14 +949,30 @@ class DifferentiableFESolver(nn.Module):
     def _plan(self) -> SolvePlan:
         return get_plan(self.mesh, _resolve_device(self._device))
 
-    def forward(self, f: torch.Tensor, load: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, f: torch.Tensor, load: Optional[torch.Tensor] = None, layout: str = "sample") -> torch.Tensor:
         """Solve for nodal u.  f: (n,), (n,1) or (B,n); returns float64 (n,) or (B,n)
         on f's device (reference solver.py:49-67 returns CPU float64).
         load (ours): (n,) or (B,n) nodal load added to the assembled load vector F on the free rows (differentiable) --
-        the M_L u_prev / dt term of a time step, point sources, a Neumann flux integrated by the caller."""
+        the M_L u_prev / dt term of a time step, point sources, a Neumann flux integrated by the caller.
+        layout (ours): "sample" = the shapes above; "node" = f, load and u are (n, B), the batch INNERMOST -- the layout
+        the kernels work in, so a caller that keeps its batch that way (an optimisation loop over kappa, say) pays no
+        transposing pass in or out (3 x 16 B per node and sample of a fwd + adjoint step); 2D meshes, same results."""
         if self.mesh.dim not in (1, 2):
             raise NotImplementedError("Only 1D and 2D supported")       # reference solver.py:67
+        if layout not in ("sample", "node"):
+            raise ValueError(f"Unknown layout: {layout!r}")
         n = self.mesh.n_nodes
+        if layout == "node":
+            if f.dim() != 2 or f.shape[0] != n or (load is not None and tuple(load.shape) != tuple(f.shape)):
+                raise ValueError(f"layout='node': f (and load) must be (n, B) with n={n}, got {tuple(f.shape)}")
+            if self.mesh.dim == 1:     # the 1D scan works sample-major: transposing views in and out
+                return self.forward(f.t(), None if load is None else load.t()).t()
+            f64 = f.to(torch.float64)
+            _SOLVERS[id(self)] = self
+            load64 = f64.new_empty(0) if load is None else load.to(torch.float64)
+            save = torch.is_grad_enabled() and (self._kappa.requires_grad or f64.requires_grad or load64.requires_grad)
+            u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, load64, id(self), save, True)
+            return u
         f64 = f.to(torch.float64)
         if f64.dim() == 2 and f64.shape == (n, 1):
             f64 = f64.reshape(n)                                          # (n,1) works in the reference too
@@ -871,7 +990,7 @@ class DifferentiableFESolver(nn.Module):
             if load64.dim() == 2 and f64.dim() == 1:
                 f64 = f64.reshape(1, n).expand(load64.shape[0], n)
         save = torch.is_grad_enabled() and (self._kappa.requires_grad or f64.requires_grad or load64.requires_grad)
-        u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, load64, id(self), save)
+        u, _token = torch.ops.diffhe.fe_solve(self._kappa, f64, load64, id(self), save, False)
         return u
 
     # reference-private names kept as aliases; both run the HIP path

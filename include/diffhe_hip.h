@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 5
+#define DIFFHE_ABI_VERSION 6
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -266,6 +266,8 @@ typedef struct diffhe_mg_level {
  *            errors are what the parity tolerance is stated in, and the energy norm bounds both far more tightly
  *            than the residual does (1024^2, f = 1: relative residual 6e-9 <-> nodal error 6e-12).  0: off.
  *   err_est  (Bp) out or NULL: the last estimate per sample
+ *   stop_rule (Bp) out or NULL (ABI v6): the rule that ended each sample -- 1 residual, 2 energy-norm estimate,
+ *            0 neither (iteration cap reached, or the direct dense path where nothing iterates)
  *   b, x     (n, Bp) right-hand side / solution (x is read only with flag bit 5; otherwise the start is 0 / FMG(b))
  *   work     diffhe_lattice_pcg_workspace_doubles(...) doubles
  *   relres, iters, status_host: as diffhe_ell_cg_solve */
@@ -273,7 +275,7 @@ long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level* levels, in
 int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
                              const double* b, double* x, int Bp, double tol, double tol_energy, int max_iter, int nu,
                              int n_coarse, const double* omegas_host, int precond_fp32, double* work, double* relres,
-                             double* err_est, int* iters, int* status_host, void* stream);
+                             double* err_est, int* iters, int* stop_rule, int* status_host, void* stream);
 /* Opt-in timing of the fused CG-step kernel (the dominant one) inside diffhe_lattice_pcg_solve's own loop, for
  * bench.py's roofline entry: enable = 1 creates two HIP events (per calling thread, the only hidden state in the
  * library, and only in this mode) and resets the counters, 0 stops, < 0 only reads.  The events bracket each launch
@@ -331,6 +333,12 @@ int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse
 int diffhe_grad_kappa_blocks(int m, int Bp);
 int diffhe_p1_grad_kappa(const int* elems, const double* k0, const double* lam, const double* u, const double* g,
                          int npe, int m, int Bp, double* dk_e, double* dk_part, double* dk_sum, void* stream);
+/* The same contraction SUMMED OVER THE BATCH, dk[e] = sum_{b < B} dk[e,b] (m doubles): the gradient of a per-element
+ * kappa field shared by all samples (reverse of solver.py:137-140 for kappa (m,)) -- what the RCCL gradient
+ * all-reduce of BASELINE config 4 carries.  Fixed summation order (bitwise reproducible); the (m, Bp) per-sample
+ * gradient is never materialised.  ABI v6. */
+int diffhe_p1_grad_kappa_shared(const int* elems, const double* k0, const double* lam, const double* u, const double* g,
+                                int npe, int m, int B, int Bp, double* dk, void* stream);
 
 /* Layout changes between the API's (B, n) and the solver's (n, Bp).
  * to_node_major: dst[i*Bp + b] = src[b*ld + i] (b < B), 0 for padding samples and

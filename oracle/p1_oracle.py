@@ -221,10 +221,29 @@ def assemble_sparse(nodes, elements, kappa, f):
 # Dirichlet elimination + solve (reference: solver.py:153-183)
 # ---------------------------------------------------------------------------
 
-def apply_bc_and_solve(K, F, bc_nodes, bc_vals):
+def refine_solution(Kff, solve_fn, x, rhs, steps):
+    """Iterative refinement of an fp64 LU solve with residuals evaluated in extended precision (numpy.longdouble,
+    x87 80-bit here): x <- x + LU^{-1}(rhs - Kff x).  Converges to the EXACT solution of the fp64-stored system --
+    the matrix the reference assembled (solver.py:89-92, :137-140) -- to ~1e-15 relative, where the plain LU result
+    (what solver.py:174 returns) carries a forward error of ~cond * eps: 7e-12 at 1D 10^4 elements, 3e-11 (u) /
+    9e-11 (dL/dkappa) at 2D 1024^2.  A yardstick for the large-size parity checks, NOT what the reference computes:
+    `tests/test_oracle_golden.py` pins its distance to the reference's own LU results (G10, G11)."""
+    if steps <= 0:
+        return x
+    A = Kff.astype(np.longdouble)
+    b = np.asarray(rhs, dtype=np.longdouble)
+    x = np.asarray(x, dtype=np.longdouble)
+    for _ in range(steps):
+        r = b - A @ x
+        x = x + solve_fn(np.asarray(r, dtype=np.float64))
+    return np.asarray(x, dtype=np.float64)
+
+
+def apply_bc_and_solve(K, F, bc_nodes, bc_vals, refine=0):
     """F_free = F[free] - sum_bc K[free,bc] g (solver.py:165-169);
     K_free = K[free][:,free] (solver.py:171); u_free = solve(K_free, F_free)
-    (solver.py:174); u[bc] = g, u[free] = u_free (solver.py:177-181)."""
+    (solver.py:174); u[bc] = g, u[free] = u_free (solver.py:177-181).
+    refine > 0: that many steps of `refine_solution` on top (ours, yardstick only)."""
     n = F.shape[0]
     bc_nodes = np.asarray(bc_nodes, dtype=np.int64)
     bc_vals = np.asarray(bc_vals, dtype=np.float64)
@@ -241,23 +260,25 @@ def apply_bc_and_solve(K, F, bc_nodes, bc_vals):
             lo, hi = Kfb.indptr[j], Kfb.indptr[j + 1]
             if hi > lo:
                 F_free[Kfb.indices[lo:hi]] -= Kfb.data[lo:hi] * bc_vals[j]
-        lu = spla.splu(K[free][:, free].tocsc())
-        u[free] = lu.solve(F_free)
+        Kff = K[free][:, free]
+        lu = spla.splu(Kff.tocsc())
+        u[free] = refine_solution(Kff, lu.solve, lu.solve(F_free), F_free, refine)
         return u, lu
     for j, b in enumerate(bc_nodes):
         F_free = F_free - K[free, b] * bc_vals[j]
-    u[free] = np.linalg.solve(K[np.ix_(free, free)], F_free)
+    Kff = K[np.ix_(free, free)]
+    u[free] = refine_solution(Kff, lambda r: np.linalg.solve(Kff, r), np.linalg.solve(Kff, F_free), F_free, refine)
     return u, None
 
 
-def solve(nodes, elements, bc_nodes, bc_vals, kappa, f, sparse=None):
+def solve(nodes, elements, bc_nodes, bc_vals, kappa, f, sparse=None, refine=0):
     """`DifferentiableFESolver.forward` (solver.py:49-67) for one sample."""
     n = np.asarray(nodes).shape[0]
     if sparse is None:
         sparse = n > 1500
     asm = assemble_sparse if sparse else assemble_dense
     K, F = asm(nodes, elements, kappa, f)
-    u, _ = apply_bc_and_solve(K, F, bc_nodes, bc_vals)
+    u, _ = apply_bc_and_solve(K, F, bc_nodes, bc_vals, refine)
     return u
 
 
@@ -265,7 +286,7 @@ def solve(nodes, elements, bc_nodes, bc_vals, kappa, f, sparse=None):
 # Adjoint (what autograd computes through solver.py:89-96,139-145,169-181)
 # ---------------------------------------------------------------------------
 
-def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sparse=None, with_cond=False):
+def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sparse=None, with_cond=False, refine=0):
     """Forward solve, then the adjoint of it for the cotangent `gbar = gbar_fn(u)`.
 
     lambda_free = K_free^{-T} gbar_free, lambda_bc = 0   (LinalgSolveExBackward of solver.py:174)
@@ -276,6 +297,9 @@ def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sp
     vector for a scalar kappa.  with_cond=True appends sum_{p,q} |lambda_p| |k0_e[p,q]| |u_q| per element: the
     magnitude of the terms each dL/dkappa_e is made of (when u is nearly constant over an element they cancel, and
     the gradient is only defined to u * that magnitude in fp64 -- used by tools/stress.py to judge gradients).
+    refine=k: k steps of `refine_solution` after the forward AND the adjoint LU solve (extended-precision residuals on
+    the reference-order assembled matrix): the yardstick with margin for the 512^2 / 1024^2 parity checks, where the
+    plain LU's own forward error (cond * eps) is most of the 1e-10 tolerance.
     """
     nodes = np.asarray(nodes, dtype=np.float64)
     elements = np.asarray(elements, dtype=np.int64)
@@ -284,14 +308,17 @@ def solve_with_adjoint(nodes, elements, bc_nodes, bc_vals, kappa, f, gbar_fn, sp
         sparse = n > 1500
     asm = assemble_sparse if sparse else assemble_dense
     K, F = asm(nodes, elements, kappa, f)
-    u, lu = apply_bc_and_solve(K, F, bc_nodes, bc_vals)
+    u, lu = apply_bc_and_solve(K, F, bc_nodes, bc_vals, refine)
     gbar = np.asarray(gbar_fn(u), dtype=np.float64)
     free = free_nodes(n, bc_nodes)
     lam = np.zeros(n)
     if lu is not None:
-        lam[free] = lu.solve(gbar[free], trans="T")
+        solve_t = lambda r: lu.solve(r, trans="T")                      # noqa: E731
+        KffT = K.tocsr()[free][:, free].T.tocsr() if refine > 0 else None
     else:
-        lam[free] = np.linalg.solve(K[np.ix_(free, free)].T, gbar[free])
+        KffT = K[np.ix_(free, free)].T
+        solve_t = lambda r: np.linalg.solve(KffT, r)                    # noqa: E731
+    lam[free] = refine_solution(KffT, solve_t, solve_t(gbar[free]), gbar[free], refine)
     k0, w = element_matrices(nodes, elements)
     lam_e = lam[elements]            # (m, npe)
     u_e = u[elements]

@@ -27,9 +27,21 @@ def _arrays(mesh):
 
 
 def _oracle_job(job):
+    """The yardstick at these sizes is the REFINED oracle (oracle.p1_oracle.refine_solution: the exact solution of the
+    reference-order assembled fp64 matrix, pinned to the reference's own LU results on G10 / G11 / G13): the plain LU
+    is itself 3e-11 (u) / 9e-11 (dL/dkappa) from it at 1024^2 -- cond * eps -- which would leave the 1e-10 asserts
+    below measuring the yardstick's noise."""
     nodes, el, bn, bv, kappa, f, scale = job
-    u, dk, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kappa, f, lambda u_: scale * u_, sparse=True)
+    u, dk, _ = orc.solve_with_adjoint(nodes, el, bn, bv, kappa, f, lambda u_: scale * u_, sparse=True, refine=2)
     return u, dk
+
+
+def _check(tag, errs, tol):
+    """Every checked sample inside `tol`; the margin is printed (and must be at least 3x: the stated tolerance is not
+    supposed to be met by a hair)."""
+    worst = max(errs)
+    print(f"{tag}: worst {worst:.2e} of {len(errs)} samples = {tol / worst:.1f}x inside {tol:g}")
+    assert worst < tol / 3.0, (tag, errs)
 
 
 def _oracle_many(mesh, kappas, fs, scale):
@@ -84,9 +96,9 @@ def test_config3_512_batch256_scalar_kappa():
     # oracle (reference-order assembly + LU) on the first, a middle and the last sample
     idx = [0, 100, B - 1]
     res = _oracle_many(mesh, [float(kappa[b]) for b in idx], [np.ones(mesh.n_nodes)] * 3, 2.0 / B)
-    for b, (uo, dk) in zip(idx, res):
-        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
-        assert abs(float(kappa.grad[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+    _check("config 3 u vs refined oracle", [rel_err(u[b].detach().cpu().numpy(), uo) for b, (uo, _) in zip(idx, res)], RTOL_U)
+    _check("config 3 dL/dkappa vs refined oracle",
+           [abs(float(kappa.grad[b]) - dk.sum()) / abs(dk.sum()) for b, (_, dk) in zip(idx, res)], RTOL_GRAD)
 
 
 @pytest.mark.timeout(900)
@@ -105,9 +117,10 @@ def test_config3_512_batch256_per_element_kappa_field():
     assert solver.last_info.not_converged == 0
     idx = [0, B - 1]
     res = _oracle_many(mesh, [kappa[b].detach().cpu().numpy() for b in idx], [np.ones(mesh.n_nodes)] * 2, 2.0 / B)
-    for b, (uo, dk) in zip(idx, res):
-        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
-        assert rel_err(kappa.grad[b].cpu().numpy(), dk) < RTOL_GRAD
+    _check("config 3 (field) u vs refined oracle", [rel_err(u[b].detach().cpu().numpy(), uo) for b, (uo, _) in zip(idx, res)],
+           RTOL_U)
+    _check("config 3 (field) dL/dkappa_e vs refined oracle",
+           [rel_err(kappa.grad[b].cpu().numpy(), dk) for b, (_, dk) in zip(idx, res)], RTOL_GRAD)
     # sum_e kappa_e dL/dkappa_e = -2 L (Euler: u is homogeneous of degree -1 in the field)
     euler = (kappa.grad * kappa.detach()).sum(dim=1) * B
     assert float(((euler + 2.0 * L).abs() / (2.0 * L)).max()) < RTOL_GRAD
@@ -132,9 +145,9 @@ def test_config4_shard_1024_batch256():
     assert float(((kappa.grad - ref).abs() / ref.abs()).max()) < RTOL_GRAD
     idx = [0, 127, B - 1]
     res = _oracle_many(mesh, [float(kappa[b]) for b in idx], [np.ones(mesh.n_nodes)] * 3, 2.0 / B)
-    for b, (uo, dk) in zip(idx, res):
-        assert rel_err(u[b].detach().cpu().numpy(), uo) < RTOL_U
-        assert abs(float(kappa.grad[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+    _check("config 4 u vs refined oracle", [rel_err(u[b].detach().cpu().numpy(), uo) for b, (uo, _) in zip(idx, res)], RTOL_U)
+    _check("config 4 dL/dkappa vs refined oracle",
+           [abs(float(kappa.grad[b]) - dk.sum()) / abs(dk.sum()) for b, (_, dk) in zip(idx, res)], RTOL_GRAD)
 
 
 @pytest.mark.timeout(900)

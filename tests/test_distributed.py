@@ -9,6 +9,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 
 import numpy as np
 import pytest
@@ -104,6 +105,170 @@ def test_single_process_is_a_noop_for_collectives():
     k = torch.tensor(2.0, requires_grad=True)
     loss, u = drv.step(torch.ones(4, 3), lambda u, lo, hi: u.sum(), shared_kappa=k)
     assert float(loss) == 6.0 and float(k.grad) == 3.0
+
+
+# --- the reduce-scatter + all-gather branch, on CPU, through an injected in-process collective -----------------------
+class _FakeNode:
+    """W virtual ranks in ONE process (threads) with real collective semantics on CPU tensors: what RCCL does
+    between the GPUs of a node, minus the wires.  Lets every line of the two-phase branch of
+    `allreduce_sum_fused` run under `-m "not gpu"` (gloo has no reduce_scatter_tensor)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = []
+
+    def rank(self, r):
+        return _FakeCollective(self, r)
+
+
+class _FakeCollective:
+    two_phase = True
+    device_only = False
+
+    def __init__(self, node, rank):
+        self.node, self.rank, self.world = node, rank, node.world
+
+    def _exchange(self, t):
+        self.node.slots[self.rank] = t
+        self.node.barrier.wait()
+        snap = list(self.node.slots)
+        return snap
+
+    def all_reduce(self, flat):
+        snap = self._exchange(flat.clone())
+        total = torch.stack(snap).sum(dim=0)
+        self.node.barrier.wait()
+        flat.copy_(total)
+        if self.rank == 0:
+            self.node.calls.append(("all_reduce", flat.numel()))
+
+    def reduce_scatter(self, out, inp):
+        assert inp.numel() == out.numel() * self.world and inp.is_contiguous()
+        snap = self._exchange(inp)                        # read-only until the second barrier
+        per = out.numel()
+        total = torch.stack([s_[self.rank * per:(self.rank + 1) * per] for s_ in snap]).sum(dim=0)
+        self.node.barrier.wait()
+        out.copy_(total)
+        if self.rank == 0:
+            self.node.calls.append(("reduce_scatter", inp.numel()))
+
+    def all_gather(self, out, inp):
+        assert out.numel() == inp.numel() * self.world
+        snap = self._exchange(inp.clone())
+        self.node.barrier.wait()
+        out.copy_(torch.cat(snap))
+        if self.rank == 0:
+            self.node.calls.append(("all_gather", out.numel()))
+
+
+def _run_ranks(world, fn):
+    node = _FakeNode(world)
+    res, err = [None] * world, []
+
+    def body(r):
+        try:
+            res[r] = fn(node.rank(r), r)
+        except BaseException as e:   # noqa: BLE001 -- re-raised below; a dead thread must not hang the barrier
+            err.append(e)
+            node.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    if err:
+        raise err[0]
+    return node, res
+
+
+@pytest.mark.parametrize("world,n", [(8, 1 << 17), (4, (1 << 17) + 4), (2, 2 * 1024 * 1024)])
+def test_two_phase_branch_runs_in_place_when_the_length_divides_the_world(world, n):
+    """A >= 1 MiB gradient whose length divides the world size: reduce-scatter straight out of the gradient's own
+    storage and all-gather straight back into it -- no staging copy, no padding; the scalar loss rides in its own
+    small all-reduce.  16.8 MB of dL/dkappa at 1024^2 (m = 2 097 152) divides 8."""
+    def rank_fn(coll, r):
+        g = torch.arange(n, dtype=torch.float64) * (r + 1)
+        loss = torch.tensor([1.0 + r], dtype=torch.float64)
+        ptr = g.data_ptr()
+        stats = {}
+        allreduce_sum_fused([loss, g], collective=coll, stats=stats)
+        assert g.data_ptr() == ptr
+        return loss, g, stats
+
+    node, res = _run_ranks(world, rank_fn)
+    tri = world * (world + 1) / 2
+    for loss, g, stats in res:
+        assert float(loss) == world + world * (world - 1) / 2
+        assert torch.equal(g, torch.arange(n, dtype=torch.float64) * tri)
+        assert stats["path"] == "all_reduce | reduce_scatter+all_gather" and stats["staged_bytes"] == 0
+        assert stats["bytes"] == 8 * n + 8 and stats["collectives"] == 3
+    assert [c[0] for c in node.calls] == ["all_reduce", "reduce_scatter", "all_gather"]
+    assert node.calls[1][1] == n and node.calls[2][1] == n          # the whole gradient, unpadded
+
+
+@pytest.mark.parametrize("world,n", [(8, (1 << 17) + 3), (3, 1 << 17)])
+def test_two_phase_branch_pads_a_length_that_does_not_divide_the_world(world, n):
+    def rank_fn(coll, r):
+        g = torch.full((n,), float(r + 1), dtype=torch.float64)
+        g[-1] = 7.0 * (r + 1)
+        stats = {}
+        allreduce_sum_fused([g], collective=coll, stats=stats)
+        return g, stats
+
+    node, res = _run_ranks(world, rank_fn)
+    tri = world * (world + 1) / 2
+    per = -(-n // world)
+    for g, stats in res:
+        assert float(g[0]) == tri and float(g[-1]) == 7.0 * tri and bool((g[:-1] == tri).all())
+        assert stats["path"] == "reduce_scatter+all_gather(staged)" and stats["staged_bytes"] == 8 * per * world
+    assert node.calls == [("reduce_scatter", per * world), ("all_gather", per * world)]
+
+
+def test_two_phase_branch_stages_a_non_contiguous_gradient_and_keeps_small_messages_fused():
+    n = 1 << 17
+
+    def rank_fn(coll, r):
+        base = torch.zeros(n, 2, dtype=torch.float64)
+        g = base[:, 0]                                   # a strided view: cannot be reduced in place
+        g += r + 1.0
+        a, b = torch.tensor([1.0 * r]), torch.tensor([[2.0, 3.0 * (r + 1)]])
+        stats = {}
+        allreduce_sum_fused([a, g, b], collective=coll, stats=stats)
+        return a, b, g, base, stats
+
+    node, res = _run_ranks(4, rank_fn)
+    for a, b, g, base, stats in res:
+        assert float(a) == 6.0 and b.tolist() == [[8.0, 30.0]]
+        assert bool((g == 10.0).all()) and bool((base[:, 1] == 0).all())
+        assert stats["path"] == "all_reduce | reduce_scatter+all_gather(staged)"
+    assert node.calls[0] == ("all_reduce", 3)            # the two small tensors in ONE message
+
+
+def test_sharded_step_reduces_a_shared_kappa_field_gradient_through_the_two_phase_branch():
+    """`ShardedBatchSolve` with the collective injected: every rank solves its shard (a toy differentiable map
+    stands in for the solve), the (m,) gradient of the shared field crosses the reduce-scatter branch and every rank
+    ends with the full-batch gradient and the global mean loss."""
+    m, B, world = 1 << 17, 8, 4
+    gen = torch.Generator().manual_seed(3)
+    f = torch.rand(B, m, generator=gen, dtype=torch.float64)
+    kap0 = 1.0 + torch.rand(m, generator=gen, dtype=torch.float64)
+
+    def rank_fn(coll, r):
+        kap = kap0.clone().requires_grad_(True)
+        drv = ShardedBatchSolve(lambda k, fl: fl / k, collective=coll)
+        assert (drv.world, drv.rank) == (world, r)
+        loss, u = drv.step(f, lambda u_, lo, hi: (u_ ** 2).sum(), shared_kappa=kap)
+        return float(loss), kap.grad.clone(), drv.last_collective, u.shape[0]
+
+    _, res = _run_ranks(world, rank_fn)
+    kap = kap0.clone().requires_grad_(True)
+    ((f / kap) ** 2).sum().div(B).backward()
+    for loss, grad, stats, nloc in res:
+        assert nloc == B // world
+        assert abs(loss - float(((f / kap0) ** 2).sum() / B)) < 1e-12 * abs(loss)
+        assert torch.allclose(grad, kap.grad, rtol=1e-13, atol=0)
+        assert stats["path"].endswith("reduce_scatter+all_gather") and stats["bytes"] == 8 * m + 8
 
 
 # --- bench.py's own multi-rank launch path -----------------------------------------------------------------

@@ -2,6 +2,7 @@
 plan/pattern construction against the oracle, API quirks of the boundary
 (SURVEY 8(b)).  No HIP kernel runs here."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -349,3 +350,33 @@ def test_lattice_gather_lists_are_the_sorted_definition():
         a, b = build_dia_pattern(nx, ny), _build_dia_pattern_sorted(nx, ny)
         for key in ("cols", "ent_ptr", "contrib"):
             assert np.array_equal(a[key], b[key]) and a[key].dtype == b[key].dtype, (nx, ny, key)
+
+
+def test_plan_host_arrays_are_built_once_per_node(tmp_path, monkeypatch):
+    """DIFFHE_PLAN_CACHE: the first rank builds and publishes the host arrays of a lattice level, the others map them."""
+    from diffhe import plan as P
+    calls = []
+
+    def build():
+        calls.append(1)
+        return P.build_dia_pattern(6, 5)
+
+    assert P.host_arrays("x", build)["contrib"].dtype == np.int32 and len(calls) == 1      # no cache dir: plain build
+    monkeypatch.setenv("DIFFHE_PLAN_CACHE", str(tmp_path))
+    first = P.host_arrays("dia_6x5", build)
+    again = P.host_arrays("dia_6x5", build)
+    assert len(calls) == 2                                                                 # the second call mapped the files
+    for key in ("cols", "ent_ptr", "contrib"):
+        assert np.array_equal(first[key], again[key]) and again[key].dtype == first[key].dtype
+    assert int(again["We"]) == 7
+    assert not [d for d in os.listdir(tmp_path) if ".tmp" in d]
+
+
+def test_gather_codes_refuse_meshes_beyond_int32():
+    """e * 64 + pq must fit an int32: 2^25 elements at most -- lattices beyond 4096^2 raise instead of wrapping."""
+    from diffhe import plan as P
+    with pytest.raises(ValueError, match="int32 gather lists"):
+        P.build_dia_pattern(4096, 4097)
+    with pytest.raises(ValueError, match="int32 gather lists"):
+        P._build_dia_pattern_sorted(8192, 2049)
+    P._check_gather_code_range(2 * 4096 * 4095)

@@ -264,6 +264,36 @@ def test_longdouble_chain_oracle_with_reference_rounding():
         assert abs(dk.sum() - float(h["dkappa"])) < 1e-11 * abs(float(h["dkappa"]))
 
 
+def test_refined_oracle_is_pinned_to_the_references_own_lu_results():
+    """`refine=` (iterative refinement with extended-precision residuals on the reference-order assembled matrix) is
+    the yardstick of the 512^2 / 1024^2 parity checks.  Pinned where the reference itself could run:
+    G10 (1D, 10^4 elements, cond 4e7): within 1e-11 of the reference's torch.linalg.solve -- the 7e-12 that remain are
+      that LU's forward error, and the refined solve agrees with the extended-precision Thomas
+      solution of the same rounded matrix to 1e-13;
+    G11 (2D 64^2) and G13 (1D 2000, gradients from the reference's autograd): unchanged to 1e-12."""
+    g = golden("g10_config2_1d_10000")
+    nodes, el, bn, bv = orc.mesh_line(int(g["n_elements"]))
+    for i in range(len(g["rows"])):
+        u = orc.solve(nodes, el, bn, bv, float(g["kappa"]), g["f"][i], sparse=True, refine=2)
+        assert rel_err(u, g["u"][i]) < 1e-11
+    exact = orc.chain_solve_longdouble(nodes, bn, bv, 1.0, g["f"][0], reference_rounding=True)
+    assert rel_err(orc.solve(nodes, el, bn, bv, 1.0, g["f"][0], sparse=True, refine=2), exact) < 1e-13
+    assert rel_err(orc.solve(nodes, el, bn, bv, 1.0, g["f"][0], sparse=True), exact) > 1e-12     # the plain LU is not
+    g = golden("g11_2d_fwd_64")
+    assert rel_err(orc.solve(*_mesh(g), float(g["kappa"]), g["f"], sparse=True, refine=2), g["u"]) < 1e-12
+    g = golden("g13_1d_grad_2000")
+    nodes, el, bn, bv = orc.mesh_line(int(g["n_elements"]))
+    for sparse in (True, False):
+        u, dk, df = orc.solve_with_adjoint(nodes, el, bn, bv, float(g["kappa"]), g["f"], lambda u_: 2 * u_,
+                                           sparse=sparse, refine=2)
+        assert rel_err(u, g["u"]) < 1e-11 and rel_err(df, g["df"]) < 1e-11
+        assert abs(dk.sum() - float(g["dkappa"])) < 1e-11 * abs(float(g["dkappa"]))
+    # dense 2D path with gradients (G4): refinement leaves a well-conditioned solve where it was
+    g = golden("g4_2d_007")
+    u, dk, df = orc.solve_with_adjoint(*_mesh(g), float(g["kappa"]), g["f"], lambda u_: 2 * u_, refine=2)
+    assert rel_err(u, g["u"]) < 1e-12 and rel_err(df, g["df"]) < 1e-11
+
+
 # ---- reaction-diffusion / heat equation oracle (oracle/heat_oracle.py): no reference counterpart, closed forms instead ----
 def test_heat_oracle_reaction_diffusion_discrete_eigenmode():
     """sin(pi x_j) is an eigenvector of the uniform 1D P1 stiffness (eigenvalue mu h, mu = (2 - 2 cos(pi h)) / h^2);

@@ -1,0 +1,298 @@
+"""Failure surfacing, determinism, thread safety and layout equivalence of the HIP solve path (SURVEY section 5:
+the reference silently returns garbage on singular systems, solver.py:174; it has no threads and no global state).
+All tests here run the real kernels through the C ABI (`-m gpu`)."""
+import threading
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from diffhe import FEMesh, DifferentiableFESolver
+from diffhe.plan import get_plan
+from oracle import p1_oracle as orc
+from _util import rel_err, RTOL_U, RTOL_GRAD
+
+pytestmark = pytest.mark.gpu
+T64 = torch.float64
+DEV = "cuda:0"
+
+
+def _unstructured(nx=40, ny=36, seed=3):
+    """rectangle(nx, ny) with jittered interior nodes, nodes renumbered at random: a general (ELL) mesh."""
+    base = FEMesh.rectangle(nx, ny)
+    rng = np.random.default_rng(seed)
+    nodes = base.nodes.numpy().copy()
+    n = len(nodes)
+    interior = np.array([i for i in range(n) if i not in base.dirichlet_nodes])
+    nodes[interior] += rng.uniform(-0.2, 0.2, size=(len(interior), 2)) / max(nx, ny)
+    perm = rng.permutation(n)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    return FEMesh(nodes=torch.from_numpy(nodes[perm]), elements=torch.from_numpy(inv[base.elements.numpy()]),
+                  dirichlet_nodes={int(inv[k]): v for k, v in base.dirichlet_nodes.items()})
+
+
+def _run(mesh, kappa0, f0, **kw):
+    kappa = kappa0.clone().to(DEV).requires_grad_(True)
+    f = f0.clone().to(DEV).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kappa, device=DEV, **kw)
+    u = solver(f)
+    (u ** 2).sum().backward()
+    return u.detach(), kappa.grad.detach(), f.grad.detach(), solver.last_info
+
+
+# ---- failure surfacing ------------------------------------------------------------------------------------------
+def test_iteration_cap_is_surfaced_not_silent():
+    """max_iter = 3 on 256^2: the CG cannot finish -- RuntimeWarning, last_info.not_converged > 0, the 'cap' bucket of
+    the stop-rule counts filled, and the output still finite (the best iterate so far)."""
+    mesh = FEMesh.rectangle(256, 256)
+    B = 64
+    gen = torch.Generator().manual_seed(1)
+    kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    solver = DifferentiableFESolver(mesh, kappa.to(DEV), device=DEV, max_iter=3)
+    with pytest.warns(RuntimeWarning, match="did not reach tol"):
+        u = solver(f.to(DEV))
+    info = solver.last_info
+    assert info.path == "lattice-mgpcg" and info.iterations == 3
+    assert info.not_converged > 0 and info.stop_rules["cap"] == info.not_converged
+    assert bool(torch.isfinite(u).all())
+    # the same call without the cap converges, and says which rule ended each sample
+    solver2 = DifferentiableFESolver(mesh, kappa.to(DEV), device=DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        solver2(f.to(DEV))
+    r = solver2.last_info.stop_rules
+    assert solver2.last_info.not_converged == 0 and r["cap"] == 0 and r["residual"] + r["energy"] == B
+
+
+def test_general_path_iteration_cap_is_surfaced():
+    mesh = _unstructured()
+    solver = DifferentiableFESolver(mesh, 1.3, device=DEV, max_iter=2)
+    with pytest.warns(RuntimeWarning, match="did not reach tol"):
+        u = solver(torch.ones(4, mesh.n_nodes, dtype=T64, device=DEV))
+    assert solver.last_info.not_converged == 4 and bool(torch.isfinite(u).all())
+
+
+def test_pure_neumann_problem_warns_instead_of_returning_garbage_silently():
+    """No Dirichlet node: K is singular.  The reference returns values of size 1e15 without a word (solver.py:174);
+    here the 1D scan returns NaN and a RuntimeWarning names the cause; the 2D path warns too and reports the
+    unconverged systems."""
+    mesh = FEMesh.line(50, bc_left=None, bc_right=None)
+    solver = DifferentiableFESolver(mesh, 1.0, device=DEV)
+    with pytest.warns(RuntimeWarning, match="singular"):
+        u = solver(torch.ones(mesh.n_nodes, dtype=T64, device=DEV))
+    assert bool(torch.isnan(u).all())
+    base = FEMesh.rectangle(24, 20)
+    mesh2 = FEMesh(nodes=base.nodes, elements=base.elements, dirichlet_nodes={})
+    solver2 = DifferentiableFESolver(mesh2, 1.0, device=DEV, max_iter=50)
+    with pytest.warns(RuntimeWarning, match="singular"):
+        solver2(torch.ones(2, mesh2.n_nodes, dtype=T64, device=DEV))
+
+
+def test_explicit_tolerance_is_honoured_over_the_energy_stop():
+    """tol= is a request on the RESIDUAL: the energy-norm stop (default on closed lattices, ends a solve at relative
+    residuals up to ~3e-7) must step aside unless tol_energy is asked for as well."""
+    mesh = FEMesh.rectangle(320, 300)
+    B = 64
+    gen = torch.Generator().manual_seed(5)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(DEV)
+    f = (1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)).to(DEV)
+    dflt = DifferentiableFESolver(mesh, kappa, device=DEV)
+    dflt(f)
+    assert dflt.last_info.stop_rules["energy"] > 0 and dflt.last_info.tol_energy > 0
+    for tol in (1e-9, 1e-12):
+        s = DifferentiableFESolver(mesh, kappa, device=DEV, tol=tol)
+        s(f)
+        info = s.last_info
+        assert info.tol_energy == 0.0 and info.stop_rules["energy"] == 0 and info.not_converged == 0
+        assert info.max_relres <= max(2.0 * tol, 1e-10), (tol, info)     # true residual; 1e-10: what fp64 can attain here
+        assert info.iterations >= dflt.last_info.iterations
+    both = DifferentiableFESolver(mesh, kappa, device=DEV, tol=1e-13, mg=dict(tol_energy=1e-11))
+    both(f)
+    assert both.last_info.tol_energy == 1e-11 and both.last_info.stop_rules["energy"] > 0
+
+
+def test_energy_stop_is_off_on_a_lattice_whose_boundary_is_partly_neumann_even_with_pinned_interior_nodes():
+    """`closed` used to be n_bc >= 2 (nx + ny), which pinned INTERIOR nodes could satisfy on a mesh whose
+    outer boundary is mostly Neumann -- the regime where the energy estimate undershoots the nodal error 40x."""
+    nx, ny = 200, 180
+    base = FEMesh.rectangle(nx, ny)
+    W = nx + 1
+    bc = {i * W: 0.25 for i in range(ny + 1)}                                   # left edge only
+    blk = [(i, j) for i in range(60, 60 + 26) for j in range(100, 100 + 26)]    # 676 pinned interior nodes (1.9 % of n)
+    bc.update({i * W + j: 0.5 for i, j in blk})
+    mesh = FEMesh(nodes=base.nodes, elements=base.elements, dirichlet_nodes=dict(sorted(bc.items())))
+    plan = get_plan(mesh, torch.device(DEV))
+    assert plan.n_bc >= 2 * (nx + ny) and not plan.closed_boundary
+    kappa = torch.tensor([0.8, 1.9], dtype=T64)
+    gen = torch.Generator().manual_seed(2)
+    f = 1 + 0.5 * torch.randn(2, mesh.n_nodes, generator=gen, dtype=T64)
+    u, gk, gf, info = _run(mesh, kappa, f)
+    assert info.path == "lattice-mgpcg" and info.tol_energy == 0.0 and info.stop_rules["energy"] == 0
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in range(2):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, float(kappa[b]), f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=2)
+        assert rel_err(u[b].cpu().numpy(), uo) < RTOL_U
+        assert abs(float(gk[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+        assert rel_err(gf[b].cpu().numpy(), df) < RTOL_GRAD
+
+
+# ---- determinism --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["lattice", "lattice-element", "general", "chain"])
+def test_two_runs_are_bitwise_identical(kind):
+    """Default (gather) path: no float atomics, fixed-order reductions -- u, dL/dkappa and dL/df of two runs are equal
+    bit for bit."""
+    gen = torch.Generator().manual_seed(11)
+    if kind.startswith("lattice"):
+        mesh, B = FEMesh.rectangle(224, 200), 64
+    elif kind == "general":
+        mesh, B = _unstructured(48, 44), 16
+    else:
+        mesh, B = FEMesh.line(3000, bc_left=1.0, bc_right=2.0), 32
+    if kind == "lattice-element":
+        kappa = torch.exp(0.3 * torch.randn(B, mesh.n_elements, generator=gen, dtype=T64))
+    else:
+        kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    a = _run(mesh, kappa, f)
+    b = _run(mesh, kappa, f)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert a[3].iterations == b[3].iterations and a[3].not_converged == 0
+
+
+# ---- two threads on one mesh ----------------------------------------------------------------------------------------
+def test_forward_and_backward_of_two_solves_on_one_mesh_overlap_safely():
+    """Two threads drive independent solves on the SAME mesh (same plan): each one's backward overlaps the other's
+    forward.  Status buffers are per calling thread and the plan's caches are locked, so both get exactly what they
+    get alone."""
+    mesh = FEMesh.rectangle(160, 144)
+    B = 64
+    gen = torch.Generator().manual_seed(21)
+    ks = [0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64) for _ in range(2)]
+    fs = [1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64) for _ in range(2)]
+    alone = [_run(mesh, ks[i], fs[i]) for i in range(2)]
+    got, errs = [[], []], []
+    gate = threading.Barrier(2)
+
+    def body(i):
+        try:
+            torch.cuda.set_device(0)
+            gate.wait()
+            for _ in range(6):
+                got[i].append(_run(mesh, ks[i], fs[i]))
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    ts = [threading.Thread(target=body, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        for r in got[i]:
+            assert torch.equal(r[0], alone[i][0]) and torch.equal(r[1], alone[i][1]) and torch.equal(r[2], alone[i][2])
+            assert r[3].iterations == alone[i][3].iterations and r[3].not_converged == 0
+
+
+# ---- second-order derivatives ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh", [FEMesh.line(40), FEMesh.rectangle(12, 10), FEMesh.rectangle(72, 64)])
+def test_double_backward_raises_instead_of_returning_a_gradient_without_graph(mesh):
+    """The reference is differentiable to any order (autograd through torch.linalg.solve, solver.py:174).  The explicit
+    adjoint here is first order: asking for a differentiable gradient must FAIL LOUDLY, not hand back a tensor with no
+    graph (whose 'Hessian-vector product' would silently be zero)."""
+    kappa = torch.tensor(1.4, dtype=T64, device=DEV, requires_grad=True)
+    f = torch.ones(mesh.n_nodes, dtype=T64, device=DEV)
+    u = DifferentiableFESolver(mesh, kappa, device=DEV)(f)
+    with pytest.raises(RuntimeError, match="second-order derivatives"):
+        torch.autograd.grad((u ** 2).sum(), kappa, create_graph=True)
+    # first order keeps working, repeatedly, on a retained graph
+    u = DifferentiableFESolver(mesh, kappa, device=DEV)(f)
+    L = (u ** 2).sum()
+    g1, = torch.autograd.grad(L, kappa, retain_graph=True)
+    g2, = torch.autograd.grad(L, kappa)
+    assert torch.equal(g1, g2) and abs(float(g1) + 2 * float(L) / 1.4) < 1e-10 * abs(float(g1))
+
+
+# ---- node-major entry -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,bc_value", [(64, 0.0), (5, 0.5), (128, 0.5)])
+@pytest.mark.parametrize("per_element", [False, True])
+def test_node_major_layout_gives_the_same_numbers(B, bc_value, per_element):
+    """forward(f, layout='node') takes and returns (n, B): the same kernels on the same data as the (B, n) API, minus the
+    transposing passes -- u, dL/dkappa and dL/df are equal bit for bit (padded batch, non-zero Dirichlet data and the
+    unpadded zero-copy case)."""
+    mesh = FEMesh.rectangle(208, 196, bc_value=bc_value)
+    n = mesh.n_nodes
+    gen = torch.Generator().manual_seed(B)
+    kappa = (torch.exp(0.3 * torch.randn(B, mesh.n_elements, generator=gen, dtype=T64)) if per_element
+             else 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64))
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    u_s, gk_s, gf_s, info_s = _run(mesh, kappa, f)
+    kap = kappa.clone().to(DEV).requires_grad_(True)
+    f_nm = f.t().contiguous().to(DEV).requires_grad_(True)
+    solver = DifferentiableFESolver(mesh, kap, device=DEV)
+    u = solver(f_nm, layout="node")
+    assert u.shape == (n, B)
+    (u ** 2).sum().backward()
+    assert torch.equal(u.detach().t(), u_s) and torch.equal(kap.grad, gk_s) and torch.equal(f_nm.grad.t(), gf_s)
+    assert solver.last_info.iterations == info_s.iterations
+    if bc_value == 0.0 and B == 64:
+        # zero Dirichlet data, no padding: u is the solver's own iterate -- an in-place edit before backward is refused
+        u2 = DifferentiableFESolver(mesh, kap, device=DEV)(f_nm, layout="node")
+        u2.mul_(2.0)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            u2.sum().backward()
+    with pytest.raises(ValueError, match="layout='node'"):
+        solver(f.to(DEV), layout="node")                       # (B, n) given where (n, B) is expected
+
+
+def test_node_major_layout_on_the_general_path_and_in_1d():
+    mesh = _unstructured(44, 40)
+    B = 8
+    gen = torch.Generator().manual_seed(4)
+    kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    u_s, gk_s, gf_s, _ = _run(mesh, kappa, f)
+    kap = kappa.clone().to(DEV).requires_grad_(True)
+    f_nm = f.t().contiguous().to(DEV).requires_grad_(True)
+    u = DifferentiableFESolver(mesh, kap, device=DEV)(f_nm, layout="node")
+    (u ** 2).sum().backward()
+    assert torch.equal(u.detach().t(), u_s) and torch.equal(kap.grad, gk_s) and torch.equal(f_nm.grad.t(), gf_s)
+    line = FEMesh.line(200, bc_left=1.0, bc_right=None)
+    f1 = 1 + 0.5 * torch.randn(3, line.n_nodes, generator=gen, dtype=T64).to(DEV)
+    s1 = DifferentiableFESolver(line, 1.7, device=DEV)
+    assert torch.equal(s1(f1.t().contiguous(), layout="node").t(), s1(f1))
+
+
+# ---- a kappa field shared by the batch: gradient summed in the kernel ---------------------------------------------------
+@pytest.mark.parametrize("mesh_kind", ["lattice", "general", "chain"])
+def test_shared_field_gradient_is_the_sum_of_the_per_sample_gradients(mesh_kind):
+    """kappa (m,) shared by B samples: dL/dkappa_e = sum_b dL/dkappa_e,b.  The batch sum happens inside
+    diffhe_p1_grad_kappa_shared (no (m, B) intermediate); compared with the per-sample-field run of the same data and
+    with the oracle's loop of reference-order solves."""
+    gen = torch.Generator().manual_seed(9)
+    if mesh_kind == "lattice":
+        mesh, B = FEMesh.rectangle(200, 196, bc_value=0.3), 70          # padded batch: 70 -> 128
+    elif mesh_kind == "general":
+        mesh, B = _unstructured(40, 36), 5
+    else:
+        mesh, B = FEMesh.line(500, bc_left=0.0, bc_right=1.0), 9
+    m, n = mesh.n_elements, mesh.n_nodes
+    field = torch.exp(0.3 * torch.randn(m, generator=gen, dtype=T64))
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    u, gk, gf, info = _run(mesh, field, f)
+    assert gk.shape == (m,) and info.not_converged == 0
+    u2, gk2, _, _ = _run(mesh, field.unsqueeze(0).expand(B, m).contiguous(), f)
+    assert rel_err(gk.cpu().numpy(), gk2.sum(dim=0).cpu().numpy()) < 1e-12
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    ref = np.zeros(m)
+    for b in range(min(B, 5)):
+        uo, dk, _ = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, field.numpy(), f[b].numpy(),
+                                           lambda u_: 2 * u_, sparse=n > 1500, refine=1)
+        assert rel_err(u[b].cpu().numpy(), uo) < RTOL_U
+        ref += dk
+    if B <= 5:
+        assert rel_err(gk.cpu().numpy(), ref) < RTOL_GRAD
