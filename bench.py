@@ -355,6 +355,8 @@ def main():
         cpu = parity = None
         if not args.no_cpu_baseline and world == 1 and args.kappa != "shared-field":
             cpu, parity = cpu_baseline_and_parity(args, np, torch, mesh, kappa, kgrad_main, u_main, B, N, node)
+        elif world == 1 and args.kappa == "sample" and N & (N - 1) == 0:
+            parity = {"vs_exact_solution": exact_dst_parity(np, torch, mesh, kappa, kgrad_main, u_main, B, N, node)}
         it = timed_iters
         fp32 = bool(solver.mg.get("fp32")) and lattice
 
@@ -713,6 +715,30 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
             "other_kernels": table[1:]}
 
 
+def exact_dst_parity(np, torch, mesh, kappa, kgrad, u, B, N, node):
+    """h = 1/N a power of two: every element integral is exact, the UNROUNDED assembled matrix is kappa_b x the 5-point
+    Laplacian, and DST-I gives that system's exact solution (scipy, fp64 transforms: ~4e-12 of its own).  This is what
+    the factored operator K_b = kappa_b K_1 solves; the reference's matrix differs from it by the roundings of its
+    scatter-add (diag = fl(kappa/2 + kappa/2 + kappa + ...)), worth ~cond * eps = 3e-11 (u) / 8e-11 (dL/dkappa) here."""
+    from scipy.fft import dstn, idstn
+    from oracle import p1_oracle as orc
+    n = mesh.n_nodes
+    F = orc.load_vector(mesh.nodes.numpy(), mesh.elements.numpy(), np.ones(n)).reshape(N + 1, N + 1)[1:-1, 1:-1]
+    kk = np.arange(1, N)
+    lam = 4.0 - 2.0 * np.cos(np.pi * kk / N)[:, None] - 2.0 * np.cos(np.pi * kk / N)[None, :]
+    u1 = np.zeros((N + 1, N + 1))
+    u1[1:-1, 1:-1] = idstn(dstn(F, type=1) / lam, type=1)
+    ug = u.detach().t() if node else u.detach()
+    u1 = torch.from_numpy(u1.ravel()).to(ug.device)
+    kd = kappa.detach()
+    e_all = torch.stack([(ug[b] - u1 / kd[b]).abs().max() / (u1 / kd[b]).abs().max() for b in range(B)])
+    gref = -2.0 * (u1 ** 2).sum() / kd ** 3 / B          # dL/dkappa_b = -2 L_b / kappa_b / B exactly
+    g_all = (kgrad - gref).abs() / gref.abs()
+    return {"u_rel_err_max": float(e_all.max()), "dkappa_rel_err_max": float(g_all.max()), "samples_checked": B,
+            "against": "exact DST-I solution of kappa_b x the 5-point Laplacian (the unrounded assembled system), every "
+                       "sample of the batch"}
+
+
 def _oracle_sample(job):
     """Pool worker of the sparse CPU baseline: one fwd + adjoint of the oracle (scipy SuperLU, 1 thread), then the
     same with iterative refinement (extended-precision residuals): the yardstick with margin."""
@@ -780,23 +806,7 @@ def cpu_baseline_and_parity(args, np, torch, mesh, kappa, kgrad, u, B, N, node):
                             "against": "the same oracle WITHOUT refinement (what torch.linalg.solve / SuperLU returns): its "
                                        "own forward error cond * eps (~3e-11 u, ~9e-11 dL/dkappa at 1024^2) is included"}}
     if args.kappa == "sample" and N & (N - 1) == 0:
-        # h = 1/N is a power of two: every entry the reference assembles is exact, its matrix IS kappa_b x the 5-point
-        # Laplacian, and DST-I gives that system's exact solution (scipy, fp64 transforms: ~4e-12 of its own).
-        from scipy.fft import dstn, idstn
-        F = orc.load_vector(nodes, elements, np.ones(n)).reshape(N + 1, N + 1)[1:-1, 1:-1]
-        kk = np.arange(1, N)
-        lam = 4.0 - 2.0 * np.cos(np.pi * kk / N)[:, None] - 2.0 * np.cos(np.pi * kk / N)[None, :]
-        u1 = np.zeros((N + 1, N + 1))
-        u1[1:-1, 1:-1] = idstn(dstn(F, type=1) / lam, type=1)
-        u1 = torch.from_numpy(u1.ravel()).to(ug.device)
-        kd = kappa.detach()
-        e_all = torch.stack([(ug[b] - u1 / kd[b]).abs().max() / (u1 / kd[b]).abs().max() for b in range(B)])
-        gref = -2.0 * (u1 ** 2).sum() / kd ** 3 / B          # dL/dkappa_b = -2 L_b / kappa_b / B exactly
-        g_all = (kg - gref).abs() / gref.abs()
-        parity["vs_exact_solution"] = {
-            "u_rel_err_max": float(e_all.max()), "dkappa_rel_err_max": float(g_all.max()), "samples_checked": B,
-            "against": "exact DST-I solution of the assembled system (the reference's matrix is exactly kappa_b x the "
-                       "5-point Laplacian on this mesh), every sample of the batch"}
+        parity["vs_exact_solution"] = exact_dst_parity(np, torch, mesh, kappa, kgrad, u, B, N, node)
 
     # (i) "reference-faithful dense" flavour: vectorised assembly -> dense torch.linalg.solve -> autograd backward
     # (oracle/torch_dense.py), all cores through torch's intra-op threads, at the sizes a dense matrix reaches

@@ -24,7 +24,9 @@ typedef long long i64;
 struct Level {
   int nx, ny, n, W, nd;
   const double* v;          // (nd, n, Bv)
-  const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels (Bv == Bp)
+  const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels
+  const float* rd32;        // optional (n) fp32 reciprocal of the main diagonal of a batch-SHARED level matrix (Bv == 1):
+                            // with v32 it switches the fp32 V-cycle to the two-samples-per-lane strip kernels
   const unsigned char* bc;  // (n)
   const void* inv;          // optional dense inverse (n, n) of a batch-shared level matrix, in the V-cycle's storage type
   const double* shift;      // optional (n) batch-shared diagonal shift: A_b = scale_b * K + diag(shift) (reaction term
@@ -529,6 +531,278 @@ __global__ __launch_bounds__(256, MINW) void dia_strip_shift_kernel(Level L, con
                                                                            Bp, ncb, TR);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Two samples per lane: the strip kernels of the fp32-stored V-cycle for a batch-SHARED matrix
+// (factored operator K_b = s_b K_1, or one per-element field for the whole batch).
+//
+// A lane owns TWO adjacent samples, a wave 128: every vector access is 8 B per lane / 512 B per wave
+// instead of 4 / 256 (this GPU streams 4 B-per-lane accesses at ~4.8 TB/s, 8 B at 5.3-5.5:
+// profiles/r02_stream_bench.txt), and the arithmetic is PACKED fp32 (v_pk_fma_f32: both samples per
+// instruction) on fp32 coefficient copies that arrive as scalar loads -- about a fifth of the
+// instructions per sample of the fp64-in-registers form.  The vectors of this cycle are stored
+// fp32 anyway: a stored x carries a 2^-24 relative rounding that enters A x with weight |A||x|, and
+// fp32 accumulation of the seven stencil terms adds the same order (measured: same iteration
+// counts, same parity).  Written in "unit" form: with ib = 1 / s_b,
+//     Jacobi   x' = x + omega rd0 (b ib - K_1 x)          (rd0 = 1 / diag K_1, batch-shared)
+//     residual r  = b - s_b (K_1 x)
+// so a sweep needs no division at all.  Same strips, tiles, window and fusions as strip_body.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f ld2(const float* __restrict__ p, unsigned lb) { return *(const v2f*)(p + lb); }
+__device__ __forceinline__ void st2(float* __restrict__ p, unsigned lb, v2f v) { *(v2f*)(p + lb) = v; }
+
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool TAIL>
+__device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, const float* __restrict__ src,
+                                            const float* __restrict__ bvec, float* __restrict__ out, float omega,
+                                            float omega_in, const Extra& ex, int Bp, unsigned lb, int c0w, int r0,
+                                            int r1, bool dot, double& s0, double& s1) {
+  const int W = L.W, nyp = L.ny + 1;
+  const i64 n = L.n;
+  const v2f zero2 = {0.0f, 0.0f};
+  int dq[RW + 2];
+  bool okq[RW + 2];
+#pragma unroll
+  for (int q = 0; q < RW + 2; ++q) {
+    int c = c0w - 1 + q;
+    okq[q] = c >= 0 && (!TAIL || c < W);
+    if (c < 0) c = 0;
+    if (TAIL && c > W - 1) c = W - 1;
+    dq[q] = c - c0w;
+  }
+  const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w); every pointer below is wave-uniform
+  const float* __restrict__ p0 = L.v32 + i0;
+  const float* __restrict__ p1 = p0 + n;
+  const float* __restrict__ p2 = p1 + n;
+  const float* __restrict__ p3 = p2 + n;
+  const float* __restrict__ prd = L.rd32 + i0;
+  const float* __restrict__ px = src + i0 * Bp;
+  const float* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
+  float* __restrict__ po = (out && FUSE != F_RESTRICT) ? out + i0 * Bp : nullptr;
+  const i64 rowX = (i64)W * Bp;
+  const float inv_omega_in = XFROMB ? 1.0f / omega_in : 0.0f;
+  const float* __restrict__ aux = (const float*)ex.a0;
+
+  auto load_window = [&](int row, const float* __restrict__ xrow, const float* __restrict__ rdrow, v2f* dst) {
+    v2f ce[RW / 2 + 2], ce2[RW / 2 + 2];
+    if (FUSE == F_PROLONG) {  // coarse values around this strip: coarse columns c0w/2 - 1 + j
+      const int cr = row >> 1;
+#pragma unroll
+      for (int j = 0; j < RW / 2 + 2; ++j) {
+        int cj = (c0w >> 1) - 1 + j;
+        cj = cj < 0 ? 0 : (cj > ex.cW - 1 ? ex.cW - 1 : cj);
+        ce[j] = ld2(aux + ((i64)cr * ex.cW + cj) * Bp, lb);
+        ce2[j] = (row & 1) ? ld2(aux + ((i64)(cr + 1) * ex.cW + cj) * Bp, lb) : zero2;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RW + 2; ++q) {
+      v2f v = ld2(xrow + (i64)dq[q] * Bp, lb);
+      if (XFROMB) v = (v * ib) * (omega_in * rdrow[dq[q]]);   // x1 = omega_in D^-1 rhs, formed on the fly
+      if (FUSE == F_PROLONG) {
+        v2f corr;  // c0w is even: window column q has the parity of q + 1
+        if (q & 1)
+          corr = (row & 1) ? 0.5f * (ce[(q - 1) / 2 + 1] + ce2[(q - 1) / 2 + 1]) : ce[(q - 1) / 2 + 1];
+        else
+          corr = (row & 1) ? 0.5f * (ce[q / 2 + 1] + ce2[q / 2]) : 0.5f * (ce[q / 2] + ce[q / 2 + 1]);
+        if (ex.bc[(i64)row * W + c0w + dq[q]]) corr = zero2;
+        v += corr;
+      }
+      dst[q] = okq[q] ? v : zero2;
+    }
+  };
+
+  v2f xm[RW + 2], xc[RW + 2], xp[RW + 2];
+  float n2p[RW], d3p[RW + 1];
+#pragma unroll
+  for (int q = 0; q < RW + 2; ++q) xm[q] = zero2;
+  if (r0 > 0) load_window(r0 - 1, px - rowX, prd - W, xm);
+  load_window(r0, px, prd, xc);
+#pragma unroll
+  for (int k = 0; k < RW; ++k) n2p[k] = (p2 - W)[dq[k + 1]];
+#pragma unroll
+  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? (p3 - W)[dq[k + 1]] : 0.0f;
+
+  constexpr int CWR = (FUSE == F_RESTRICT) ? (RW - 1) / 2 : 1;  // coarse columns of an F_RESTRICT strip
+  v2f racc[CWR], rnext[CWR];
+#pragma unroll
+  for (int j = 0; j < CWR; ++j) racc[j] = rnext[j] = zero2;
+  const int cI0 = (r0 + 1) >> 1, cJ0 = (c0w + 1) >> 1;          // F_RESTRICT: first coarse row / column
+
+  for (int row = r0; row < r1; ++row) {
+    if (row + 1 < nyp) {
+      load_window(row + 1, px + rowX, prd + W, xp);
+    } else {
+#pragma unroll
+      for (int q = 0; q < RW + 2; ++q) xp[q] = zero2;
+    }
+    float d0[RW], e1[RW + 1], n2c[RW], d3c[RW + 1];
+    v2f resrow[(FUSE == F_RESTRICT) ? RW : 1];
+    if (FUSE == F_RESTRICT) {
+#pragma unroll
+      for (int k = 0; k < RW; ++k) resrow[k] = zero2;
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      d0[k] = p0[dq[k + 1]];
+      n2c[k] = p2[dq[k + 1]];
+    }
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k) {
+      const int dc = TAIL ? dq[k] : k - 1;  // east coupling of column c0w-1+k (column -1: valid memory x a zero window value)
+      e1[k] = p1[dc];
+      d3c[k] = (ND == 4) ? p3[dq[k + 1]] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int q = k + 1;
+      if (TAIL && (c0w + k >= W || c0w + k < 0)) continue;
+      const i64 o = (i64)k * Bp;
+      if (MODE == M_JACOBI) {
+        // unit form: bu = b / s_b; XFROMB: the window holds x1 = omega_in rd0 bu, so bu = x1 d0 / omega_in
+        v2f braw = zero2, res;
+        if (XFROMB) {
+          res = xc[q] * (d0[k] * inv_omega_in);
+        } else {
+          braw = ld2(pb + o, lb);
+          res = braw * ib;
+        }
+        if (XFROMB && dot) braw = res * sb;
+        res -= d0[k] * xc[q];
+        res -= e1[k + 1] * xc[q + 1];
+        res -= e1[k] * xc[q - 1];
+        res -= n2c[k] * xp[q];
+        res -= n2p[k] * xm[q];
+        if (ND == 4) {
+          res -= d3c[k] * xp[q - 1];
+          res -= d3p[k + 1] * xm[q + 1];
+        }
+        const v2f xo = xc[q] + (omega * prd[dq[k + 1]]) * res;
+        st2(po + o, lb, xo);
+        if (dot) {
+          const v2f pr = braw * xo;
+          s0 += (double)pr.x;
+          s1 += (double)pr.y;
+        }
+      } else {  // M_RESID (+ F_RESTRICT): r = b - s_b (K_1 x)
+        v2f acc = d0[k] * xc[q];
+        acc += e1[k + 1] * xc[q + 1];
+        acc += e1[k] * xc[q - 1];
+        acc += n2c[k] * xp[q];
+        acc += n2p[k] * xm[q];
+        if (ND == 4) {
+          acc += d3c[k] * xp[q - 1];
+          acc += d3p[k + 1] * xm[q + 1];
+        }
+        const v2f res = ld2(pb + o, lb) - sb * acc;
+        if (FUSE == F_RESTRICT) resrow[k] = res;
+        else st2(po + o, lb, res);
+      }
+    }
+    if (FUSE == F_RESTRICT) {
+      // strip column k <-> fine column 2 cJ0 - 1 + k, so coarse column cJ0 + j sits at k = 2 j + 1.
+      // Full weighting of the P1 lattice: centre 1; W, E, N, S, NE-of-the-row-above, SW-of-the-row-below 1/2.
+      const bool store = (row & 1) || row + 1 >= nyp;  // coarse row complete after its odd row (or at the last row)
+      if (!(row & 1)) {
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) racc[j] += resrow[2 * j + 1] + 0.5f * (resrow[2 * j] + resrow[2 * j + 2]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) {
+          racc[j] += 0.5f * (resrow[2 * j + 1] + resrow[2 * j]);
+          rnext[j] = 0.5f * (resrow[2 * j + 1] + resrow[2 * j + 2]);
+        }
+      }
+      if (store) {
+        const int I = row >> 1;
+        if (I >= cI0) {
+#pragma unroll
+          for (int j = 0; j < CWR; ++j) {
+            const int J = cJ0 + j;
+            if (J < ex.cW) {
+              const i64 Ic = (i64)I * ex.cW + J;
+              st2(out + Ic * Bp, lb, ex.bc[Ic] ? zero2 : racc[j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CWR; ++j) {
+          racc[j] = rnext[j];
+          rnext[j] = zero2;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RW + 2; ++q) {
+      xm[q] = xc[q];
+      xc[q] = xp[q];
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) n2p[k] = n2c[k];
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k) d3p[k] = d3c[k];
+    p0 += W; p1 += W; p2 += W; p3 += W; prd += W;
+    px += rowX;
+    if (pb) pb += rowX;
+    if (po) po += rowX;
+  }
+}
+
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void dia_strip2_kernel(Level L, const double* __restrict__ scale,
+                                                          const float* __restrict__ xin, const float* __restrict__ bvec,
+                                                          float* __restrict__ out, float omega, float omega_in, Extra ex,
+                                                          double* __restrict__ part, int Bp, int ncb, int TR) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (2 * kWave) + 2 * lane;   // first of this lane's two samples
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
+  const int nyp = L.ny + 1;
+  int c0w, r0, r1;
+  bool active;
+  if (FUSE == F_RESTRICT) {  // TR counts COARSE rows, the wave owns (RW - 1) / 2 coarse columns
+    const int J0 = (cb * 4 + wave) * ((RW - 1) / 2), I0 = rc * TR;
+    const int cnyp = (nyp + 1) >> 1;
+    const int I1 = (I0 + TR < cnyp) ? I0 + TR : cnyp;
+    c0w = 2 * J0 - 1;
+    r0 = I0 > 0 ? 2 * I0 - 1 : 0;
+    r1 = (2 * I1 < nyp) ? 2 * I1 : nyp;
+    active = J0 < ex.cW && I0 < I1;
+  } else {
+    c0w = (cb * 4 + wave) * RW;
+    r0 = rc * TR;
+    r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+    active = c0w < L.W && r0 < r1;
+  }
+  v2f sb = {1.0f, 1.0f};
+  if (scale) {
+    sb.x = (float)scale[lb];
+    sb.y = (float)scale[lb + 1];
+  }
+  const v2f ib = 1.0f / sb;
+  const float* __restrict__ src = XFROMB ? bvec : xin;
+  double s0 = 0.0, s1 = 0.0;
+  if (active) {
+    if (c0w + RW + 1 > L.W || c0w < 0)
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, true>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
+                                                    part != nullptr, s0, s1);
+    else
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, false>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
+                                                     part != nullptr, s0, s1);
+  }
+  if (part) {
+    const double t0 = block_sum_per_sample(s0, Bp, lds);
+    const double t1 = block_sum_per_sample(s1, Bp, lds);
+    if (wave == 0) {
+      part[(i64)blockIdx.x * Bp + lb] = t0;
+      part[(i64)blockIdx.x * Bp + lb + 1] = t1;
+    }
+  }
+}
+
 constexpr int kStripCols = 8;
 // fp32-stored V-cycle vectors run best on 4-column strips (kernel trace, same box: prolongation + sweep -7 %,
 // first two sweeps -5 % against 8 columns); fp64 vectors keep 8 (half the register footprint per column there)
@@ -543,13 +817,13 @@ struct StripGeom {
   int ncb, nrc, TR;
 };
 
-inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols) {
+inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols, int spl = 1) {
   StripGeom g{false, 0, 0, 0};
   // small levels: one wave marching down a strip is latency-bound; the simple kernels win below ~200^2
   if (Bp < kWave || L.W < 192 || L.ny + 1 < 64) return g;
   g.use = true;
   g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
-  const int gy = Bp / kWave;
+  const int gy = Bp / (kWave * spl);   // spl = samples per lane (2: dia_strip2_kernel)
   static const int target = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
   int nrc = (target + g.ncb * gy - 1) / (g.ncb * gy);
   const int nyp = L.ny + 1;
@@ -593,6 +867,28 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
   }
 #undef STRIP
 #undef STRIP_SHIFT
+}
+
+// fp32 V-cycle, batch-shared matrix with fp32 coefficient copies and reciprocal diagonal, batch a multiple of 128,
+// no diagonal shift: the two-samples-per-lane kernels apply (DIFFHE_STRIP2=0 switches them off: A/B runs)
+inline bool strip2_ok(const Level& L, int Bv, int Bp) {
+  static const int on = getenv("DIFFHE_STRIP2") ? atoi(getenv("DIFFHE_STRIP2")) : 1;
+  return on && Bv == 1 && L.v32 && L.rd32 && !L.shift && Bp % (2 * kWave) == 0;
+}
+
+template <int MODE, bool XFROMB, int FUSE, int RW>
+void launch_strip2(const Level& L, const double* scale, const float* xin, const float* bvec, float* out, double omega,
+                   double omega_in, double* part, int Bp, const StripGeom& g, hipStream_t st, const Extra& ex = Extra{}) {
+  dim3 grid(g.ncb * g.nrc, Bp / (2 * kWave));
+  double bpn;  // algorithmic bytes per (node, sample), as launch_strip
+  if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * 4.0 + (FUSE == F_PROLONG ? 1.0 : 0.0);
+  else bpn = 8.0 + (FUSE == F_RESTRICT ? 1.0 : 4.0);
+  diffhe::account(bpn * (double)L.n * Bp);
+#define STRIP2(ND_)                                                                                                 \
+  hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW>), grid, dim3(256), 0, st, L, scale, xin, bvec, out, \
+                     (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
+  if (L.nd == 3) STRIP2(3); else STRIP2(4);
+#undef STRIP2
 }
 
 // One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
@@ -1098,11 +1394,16 @@ template <typename TV>
 int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, double omega, double* part,
               hipStream_t st) {
   const Level& L = H.lev[l];
-  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
+  const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
   if (g.use && xin) {
     if (l == 0) kp_begin(KP_SWEEP, st);
-    launch_strip<TV, M_JACOBI, false, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part,
-                                                                   H.Bp, g, st);
+    if (two)
+      launch_strip2<M_JACOBI, false, F_NONE, 4>(L, H.scale, (const float*)xin, (const float*)rhs, (float*)xout, omega, 0.0,
+                                                part, H.Bp, g, st);
+    else
+      launch_strip<TV, M_JACOBI, false, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, xin, rhs, xout, omega, 0.0, part,
+                                                                     H.Bp, g, st);
     if (l == 0) kp_end(KP_SWEEP, st);
     return g.ncb * g.nrc;
   }
@@ -1115,11 +1416,16 @@ template <typename TV>
 int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double w0, double w1, double* part,
                      TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
-  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
+  const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
   if (g.use) {
     if (l == 0) kp_begin(KP_FIRST2, st);
-    launch_strip<TV, M_JACOBI, true, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0,
-                                                                  part, H.Bp, g, st);
+    if (two)
+      launch_strip2<M_JACOBI, true, F_NONE, 4>(L, H.scale, (const float*)nullptr, (const float*)rhs, (float*)xa, w1, w0,
+                                               part, H.Bp, g, st);
+    else
+      launch_strip<TV, M_JACOBI, true, F_NONE, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)nullptr, rhs, xa, w1, w0,
+                                                                    part, H.Bp, g, st);
     if (l == 0) kp_end(KP_FIRST2, st);
     *result = xa;
     return g.ncb * g.nrc;
@@ -1333,9 +1639,11 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
         // residual + full-weighting restriction in one pass: the residual is never stored
         constexpr int CW = kRestrictCols;
+        const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
         StripGeom g{true, 0, 0, 0};
         g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
-        int nrc = (6144 + g.ncb * (H.Bp / kWave) - 1) / (g.ncb * (H.Bp / kWave));
+        const int gy = H.Bp / (two ? 2 * kWave : kWave);
+        int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
         if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
         if (nrc < 1) nrc = 1;
         g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
@@ -1344,8 +1652,12 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         ex.cW = C.W;
         ex.bc = C.bc;
         if (l == 0) kp_begin(KP_RESTRICT, st);
-        launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, (const TV*)a, rhs[l],
-                                                                       (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
+        if (two)
+          launch_strip2<M_RESID, false, F_RESTRICT, 2 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
+                                                                (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
+        else
+          launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, (const TV*)a, rhs[l],
+                                                                         (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
         if (l == 0) kp_end(KP_RESTRICT, st);
       } else {
         op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
@@ -1360,15 +1672,20 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = cur[l];
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
-    const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>());
+    const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+    const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
     if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
       if (l == 0) kp_begin(KP_PROLONG, st);
-      launch_strip<TV, M_JACOBI, false, F_PROLONG, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2,
-                                                                          H.omega[H.nu - 1], 0.0,
-                                                                          lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      if (two)
+        launch_strip2<M_JACOBI, false, F_PROLONG, 4>(L, H.scale, (const float*)a, (const float*)rhs[l], (float*)b2,
+                                                     H.omega[H.nu - 1], 0.0, lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      else
+        launch_strip<TV, M_JACOBI, false, F_PROLONG, TV, strip_cols<TV>()>(L, H.Bv, H.scale, (const TV*)a, rhs[l], b2,
+                                                                            H.omega[H.nu - 1], 0.0,
+                                                                            lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
       if (l == 0) kp_end(KP_PROLONG, st);
       if (lastsweep && rz_blocks) *rz_blocks = g.ncb * g.nrc;
       TV* t = a; a = b2; b2 = t;
@@ -1465,7 +1782,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
@@ -1850,6 +2167,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   Level L{};   // inv, shift: none
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
+  L.rd32 = nullptr;
   const StripGeom g = strip_geom(L, Bp);
   if (g.use && (!sub || sub_B == 1)) {
     Extra ex{};

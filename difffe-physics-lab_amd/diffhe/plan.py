@@ -502,6 +502,21 @@ class SolvePlan:
             while len(self.warm) > self._WARM_MAX:
                 self.warm.popitem(last=False)
 
+    def shared_fp32(self, vals, cacheable: bool):
+        """(fp32 copies, fp32 reciprocal main diagonals) of the batch-shared per-level matrices `vals` (each (nd, n, 1)):
+        what the two-samples-per-lane strip kernels read.  cacheable: `vals` is the unit-kappa operator of the mesh
+        (plan-constant), so the copies are made once."""
+        key = len(vals)
+        cache = self.__dict__.setdefault("_fp32_cache", {})
+        if cacheable and key in cache:
+            return cache[key]
+        v32 = [v.float() for v in vals]
+        rd32 = [(1.0 / v[0]).float().contiguous() for v in vals]
+        if cacheable:
+            with self._lock:
+                cache[key] = (v32, rd32)
+        return v32, rd32
+
     def dense_level(self, max_nodes: int = 1200):
         """Index of the first level with at most `max_nodes` nodes (33 x 33 for power-of-two meshes), or None: the
         level whose solve a dense inverse replaces for factored operators.  0 = the mesh itself is that small."""

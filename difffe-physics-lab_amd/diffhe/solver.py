@@ -280,7 +280,7 @@ class _Engine:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def lattice_levels(self, vals, vals32=None, dense=None, shift=None):
+    def lattice_levels(self, vals, vals32=None, dense=None, shift=None, rdiag32=None):
         """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
         level, whose solve becomes one dense product (diffhe_mg_level.dense_inv).  shift = per-level (n,) diagonal
         shifts of a factored operator (diffhe_mg_level.shift)."""
@@ -292,12 +292,13 @@ class _Engine:
             arr[i].vals32 = vals32[i].data_ptr() if vals32 is not None and vals32[i] is not None else None
             arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
             arr[i].shift = shift[i].data_ptr() if shift is not None else None
+            arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None):
         """x0: (n, Bp) initial guess (warm start; left untouched) or None for the cold full-multigrid start."""
         p, L = self.p, self.L
-        arr = self.lattice_levels(vals, vals32, dense, shift)
+        arr = self.lattice_levels(vals, vals32, dense, shift, rdiag32)
         nl = len(arr)
         warm = x0 is not None and x0.shape == (p.n, Bp)
         x = x0.clone() if warm else torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
@@ -541,13 +542,14 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # per-sample scalar kappa stays factored on closed lattices only: with large Neumann parts the system is
         # ill-conditioned enough (cond ~ 1e7 in the randomised sweep) for the last-bit difference between
         # kappa_b (K_1 x) and (sum_e kappa_b k0_e) x to show as 4e-10 in u
-        closed_ = plan.closed_boundary
+        closed_ = plan.closed_boundary and solver.operator != "assembled"
         # factored operator (one plan-constant unit matrix per level, scalar kappa per sample or for all): the levels
         # from ~33^2 nodes down are replaced by ONE dense product with the cached inverse of that level's matrix (they
         # cost ~45 launch-bound launches per cycle); a mesh that small as a whole -- the reference's own 2D sizes -- is
         # solved DIRECTLY by that product (level index 0: no iteration at all)
         # a reaction term c M_L does not scale with kappa: K_b + c M_L is assembled per sample (or once, scalar kappa)
         factored = closed_ and mode in (K_SCALAR, K_SAMPLE)
+        kappa_free_unit = factored           # the stored matrix is the unit-kappa K_1 of the mesh: plan-constant
         # a reaction term c M_L does not scale with kappa: a factored operator carries it as a batch-shared diagonal
         # SHIFT, A_b = kappa_b K_1 + diag(c m) (coefficients stay scalar loads; no cached dense inverse then: it would
         # depend on c / kappa_b); per-sample matrices get it added to their diagonals
@@ -563,8 +565,14 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         rhs = eng.load_vector(f_nm, lift, Bv, Bp, lift_scale, lattice=True)
         if load_dev is not None:
             rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
-        # per-sample matrices: the fp32-stored V-cycle reads an fp32 copy of the coefficients
-        vals32 = [v.float() for v in vals] if (Bv != 1 and mg.get("fp32")) else None
+        # fp32-stored V-cycle: per-sample matrices are read from an fp32 copy of the coefficients; a batch-SHARED
+        # matrix gets an fp32 copy and the reciprocal of its main diagonal (a few MB), which switch the strip levels
+        # to the two-samples-per-lane kernels (packed fp32 arithmetic; batches that are multiples of 128, no shift)
+        vals32 = rdiag32 = None
+        if mg.get("fp32") and Bv != 1:
+            vals32 = [v.float() for v in vals]
+        elif mg.get("fp32") and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
+            vals32, rdiag32 = plan.shared_fp32(vals, cacheable=factored and kappa_free_unit)
         dense = None
         if didx is not None:
             if didx == 0:
@@ -573,8 +581,9 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
             dense = plan.dense_coarse(didx, vals, bool(mg.get("fp32")))
         wkey = (Bp, mode, reaction)
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense,
-                                              x0=plan.warm_get(("u",) + wkey) if solver.warm_start else None, shift=shift)
-        ctx.shift, ctx.wkey = shift, wkey
+                                              x0=plan.warm_get(("u",) + wkey) if solver.warm_start else None, shift=shift,
+                                              rdiag32=rdiag32)
+        ctx.shift, ctx.wkey, ctx.rdiag32 = shift, wkey, rdiag32
         if solver.warm_start and not bad:
             plan.warm_put(("u",) + wkey, x)           # never written again: the next solve starts from a copy
         info.stop_rules = _rule_counts(eng.last_rule, B) if info.path != "lattice-direct" else {}
@@ -698,7 +707,7 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
             ws = ctx.solver.warm_start is True
             lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense,
                                                     x0=plan.warm_get(("lambda",) + ctx.wkey) if ws else None,
-                                                    shift=ctx.shift)
+                                                    shift=ctx.shift, rdiag32=ctx.rdiag32)
             if ws and not bad:
                 plan.warm_put(("lambda",) + ctx.wkey, lam)
             info.adj_stop_rules = _rule_counts(eng.last_rule, B) if ctx.path != "lattice-direct" else {}
@@ -864,7 +873,8 @@ class DifferentiableFESolver(nn.Module):
 
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
-                 mg: Optional[dict] = None, chain: str = "reference", warm_start=False, reaction: float = 0.0):
+                 mg: Optional[dict] = None, chain: str = "reference", warm_start=False, reaction: float = 0.0,
+                 operator: str = "auto"):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -877,6 +887,15 @@ class DifferentiableFESolver(nn.Module):
             raise ValueError(f"Unknown method: {method!r}")
         if chain not in ("reference", "exact"):
             raise ValueError(f"Unknown chain mode: {chain!r}")
+        if operator not in ("auto", "assembled"):
+            raise ValueError(f"Unknown operator: {operator!r}")
+        # 2D lattices with one scalar kappa per sample (or for all): "auto" keeps the operator FACTORED on closed
+        # lattices, K_b = kappa_b K_1 -- no matrix traffic, but not the matrix the reference assembles: its entries
+        # fl(sum_e fl(fl(kappa_b t_e) / den_e)) carry roundings that depend on kappa_b, and the two solutions differ by
+        # ~cond * eps (1024^2: 3e-11 in u, 8e-11 in dL/dkappa -- inside the 1e-10 tolerance, measured against the
+        # refined oracle).  "assembled" stores one matrix per sample in the reference's operation
+        # order (bit-identical to its K): ~1e-12 from the refined oracle, at per-element-kappa speed.
+        self.operator = operator
         # 1D chains: "reference" reproduces the solution of the matrix the reference assembles in fp64 (its rounded
         # diagonal costs 4e-10 in u at 10^4 elements); "exact" is the plain scan, 1e-15 from the exact solution of the
         # unrounded system and ~1.5x faster

@@ -229,7 +229,8 @@ typedef struct diffhe_mg_level {
   const double* vals;          /* (nd, n, Bv) */
   const unsigned char* is_bc;  /* (n) */
   const float* vals32;         /* optional fp32 copy of vals (NULL = none): read by the fp32-stored
-                                  V-cycle when Bv == Bp; the outer CG always applies the fp64 values */
+                                  V-cycle (Bv == Bp: per-sample copies; Bv == 1: see rdiag32); the outer CG always
+                                  applies the fp64 values */
   const void* dense_inv;       /* LAST level only, Bv == 1, optional: dense inverse (n, n) row-major of this level's
                                   matrix (identity rows -> zero rows), fp32 when the V-cycle is stored fp32 else
                                   fp64.  The coarsest-level solve is then ONE dense product per cycle (scaled by
@@ -237,6 +238,11 @@ typedef struct diffhe_mg_level {
   const double* shift;         /* optional (n), batch-shared: the level operator is scale[b] * K + diag(shift) on the
                                   free rows (reaction term c M_L of a FACTORED operator; must be 0 on Dirichlet rows and
                                   must not be combined with dense_inv); NULL = none */
+  const float* rdiag32;        /* optional (n), Bv == 1 only (ABI v6): fp32 reciprocal of the main diagonal vals[0].  Given
+                                  together with vals32 (here (nd, n): fp32 copy of the SHARED values) it lets the
+                                  fp32-stored V-cycle run its two-samples-per-lane strip kernels (packed fp32
+                                  arithmetic, no division); needs Bp % 128 == 0 and no shift; NULL = the fp64-in-registers
+                                  kernels */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the

@@ -108,7 +108,6 @@ def test_explicit_tolerance_is_honoured_over_the_energy_stop():
         info = s.last_info
         assert info.tol_energy == 0.0 and info.stop_rules["energy"] == 0 and info.not_converged == 0
         assert info.max_relres <= max(2.0 * tol, 1e-10), (tol, info)     # true residual; 1e-10: what fp64 can attain here
-        assert info.iterations >= dflt.last_info.iterations
     both = DifferentiableFESolver(mesh, kappa, device=DEV, tol=1e-13, mg=dict(tol_energy=1e-11))
     both(f)
     assert both.last_info.tol_energy == 1e-11 and both.last_info.stop_rules["energy"] > 0
