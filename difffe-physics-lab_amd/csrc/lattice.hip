@@ -26,7 +26,8 @@ struct Level {
   const double* v;          // (nd, n, Bv)
   const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels
   const float* rd32;        // optional (n) fp32 reciprocal of the main diagonal of a batch-SHARED level matrix (Bv == 1):
-                            // with v32 it switches the fp32 V-cycle to the two-samples-per-lane strip kernels
+                            // with v32 and mk32 it switches the fp32 V-cycle to the two-samples-per-lane strip kernels
+  const float* mk32;        // (n) 0.0f on Dirichlet rows, 1.0f elsewhere (scalar-loadable form of bc)
   const unsigned char* bc;  // (n)
   const void* inv;          // optional dense inverse (n, n) of a batch-shared level matrix, in the V-cycle's storage type
   const double* shift;      // optional (n) batch-shared diagonal shift: A_b = scale_b * K + diag(shift) (reaction term
@@ -552,53 +553,85 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f ld2(const float* __restrict__ p, unsigned lb) { return *(const v2f*)(p + lb); }
 __device__ __forceinline__ void st2(float* __restrict__ p, unsigned lb, v2f v) { *(v2f*)(p + lb) = v; }
+// Buffer addressing: one resource descriptor per stream (base = the tile's first window row, one column left of the
+// strip), a loop-invariant 32-bit per-lane byte offset per column (VGPR) and a wave-uniform 32-bit byte offset per
+// row (SGPR, one s_add per iteration): "buffer_load_dwordx2 v, v_off, s[rsrc], s_row offen" -- no 64-bit address
+// arithmetic per access (the flat-pointer form cost a v_lshl_add_u64 per load and ~50 scalar adds per row).
+// Offsets are relative to the TILE, so they stay far below 2^32 whatever the size of the vector (checked on the host).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ v2f bld(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, v2f v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
+}
 
-template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool TAIL>
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool TAIL, bool DOT>
 __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, const float* __restrict__ src,
                                             const float* __restrict__ bvec, float* __restrict__ out, float omega,
                                             float omega_in, const Extra& ex, int Bp, unsigned lb, int c0w, int r0,
-                                            int r1, bool dot, double& s0, double& s1) {
+                                            int r1, double& s0, double& s1) {
   const int W = L.W, nyp = L.ny + 1;
   const i64 n = L.n;
   const v2f zero2 = {0.0f, 0.0f};
+  // Bases sit at window row r0 - 1, one column LEFT of the strip: window column q (grid column c0w - 1 + q) has the
+  // non-negative lane offset (dq[q] + 1) * Bp, row `row` the uniform offset (row - r0 + 1) * W * Bp.
   int dq[RW + 2];
   bool okq[RW + 2];
+  unsigned offq[RW + 2];
 #pragma unroll
   for (int q = 0; q < RW + 2; ++q) {
     int c = c0w - 1 + q;
-    okq[q] = c >= 0 && (!TAIL || c < W);
-    if (c < 0) c = 0;
+    okq[q] = !TAIL || (c >= 0 && c < W);   // interior strips (TAIL = false) have every window column inside the grid
+    if (TAIL && c < 0) c = 0;
     if (TAIL && c > W - 1) c = W - 1;
     dq[q] = c - c0w;
+    offq[q] = 4u * ((unsigned)((dq[q] + 1) * Bp) + lb);   // bytes
   }
-  const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w); every pointer below is wave-uniform
+  const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
   const float* __restrict__ p0 = L.v32 + i0;
   const float* __restrict__ p1 = p0 + n;
   const float* __restrict__ p2 = p1 + n;
   const float* __restrict__ p3 = p2 + n;
   const float* __restrict__ prd = L.rd32 + i0;
-  const float* __restrict__ px = src + i0 * Bp;
-  const float* __restrict__ pb = bvec ? bvec + i0 * Bp : nullptr;
-  float* __restrict__ po = (out && FUSE != F_RESTRICT) ? out + i0 * Bp : nullptr;
-  const i64 rowX = (i64)W * Bp;
+  const float* __restrict__ pmk = (FUSE == F_PROLONG) ? L.mk32 + i0 : nullptr;
+  const i64 tile0 = (i0 - W - 1) * Bp;                                     // element (r0 - 1, c0w - 1)
+  const rsrc_t rx = make_rsrc(src + tile0);
+  const rsrc_t rb = make_rsrc(bvec ? bvec + tile0 : nullptr);
+  const rsrc_t ro = make_rsrc((out && FUSE != F_RESTRICT) ? out + tile0 : nullptr);
+  const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;                   // bytes per grid row
   const float inv_omega_in = XFROMB ? 1.0f / omega_in : 0.0f;
   const float* __restrict__ aux = (const float*)ex.a0;
+  unsigned offc[RW / 2 + 2];   // F_PROLONG: coarse columns c0w/2 - 1 + j (clamped), as offsets into a coarse row
+#pragma unroll
+  for (int j = 0; j < RW / 2 + 2; ++j) {
+    int cj = (c0w >> 1) - 1 + j;
+    cj = cj < 0 ? 0 : (cj > ex.cW - 1 ? ex.cW - 1 : cj);
+    offc[j] = (FUSE == F_PROLONG) ? 4u * ((unsigned)(cj * Bp) + lb) : 0u;
+  }
+  const int cr0 = (r0 > 0 ? r0 - 1 : 0) >> 1;                              // first coarse row this tile reads
+  const rsrc_t rc = make_rsrc(FUSE == F_PROLONG ? aux + (i64)cr0 * ex.cW * Bp : nullptr);
+  const unsigned rowCB = 4u * (unsigned)ex.cW * (unsigned)Bp;
 
-  auto load_window = [&](int row, const float* __restrict__ xrow, const float* __restrict__ rdrow, v2f* dst) {
+  // sx = byte offset of window row `row` in the tile
+  auto load_window = [&](int row, unsigned sx, const float* __restrict__ rdrow, const float* __restrict__ mkrow,
+                         v2f* dst) {
     v2f ce[RW / 2 + 2], ce2[RW / 2 + 2];
-    if (FUSE == F_PROLONG) {  // coarse values around this strip: coarse columns c0w/2 - 1 + j
-      const int cr = row >> 1;
+    if (FUSE == F_PROLONG) {  // coarse values around this strip
+      const unsigned sc = (unsigned)((row >> 1) - cr0) * rowCB;
 #pragma unroll
       for (int j = 0; j < RW / 2 + 2; ++j) {
-        int cj = (c0w >> 1) - 1 + j;
-        cj = cj < 0 ? 0 : (cj > ex.cW - 1 ? ex.cW - 1 : cj);
-        ce[j] = ld2(aux + ((i64)cr * ex.cW + cj) * Bp, lb);
-        ce2[j] = (row & 1) ? ld2(aux + ((i64)(cr + 1) * ex.cW + cj) * Bp, lb) : zero2;
+        ce[j] = bld(rc, offc[j], sc);
+        ce2[j] = (row & 1) ? bld(rc, offc[j], sc + rowCB) : zero2;
       }
     }
 #pragma unroll
     for (int q = 0; q < RW + 2; ++q) {
-      v2f v = ld2(xrow + (i64)dq[q] * Bp, lb);
+      v2f v = bld(rx, offq[q], sx);
       if (XFROMB) v = (v * ib) * (omega_in * rdrow[dq[q]]);   // x1 = omega_in D^-1 rhs, formed on the fly
       if (FUSE == F_PROLONG) {
         v2f corr;  // c0w is even: window column q has the parity of q + 1
@@ -606,8 +639,7 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
           corr = (row & 1) ? 0.5f * (ce[(q - 1) / 2 + 1] + ce2[(q - 1) / 2 + 1]) : ce[(q - 1) / 2 + 1];
         else
           corr = (row & 1) ? 0.5f * (ce[q / 2 + 1] + ce2[q / 2]) : 0.5f * (ce[q / 2] + ce[q / 2 + 1]);
-        if (ex.bc[(i64)row * W + c0w + dq[q]]) corr = zero2;
-        v += corr;
+        v += mkrow[dq[q]] * corr;   // mask: 0 on Dirichlet rows (no correction there), 1 elsewhere
       }
       dst[q] = okq[q] ? v : zero2;
     }
@@ -617,8 +649,9 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
   float n2p[RW], d3p[RW + 1];
 #pragma unroll
   for (int q = 0; q < RW + 2; ++q) xm[q] = zero2;
-  if (r0 > 0) load_window(r0 - 1, px - rowX, prd - W, xm);
-  load_window(r0, px, prd, xc);
+  if (r0 > 0) load_window(r0 - 1, 0u, prd - W, pmk ? pmk - W : nullptr, xm);
+  load_window(r0, rowB, prd, pmk, xc);
+  unsigned sx = rowB;                                                      // byte offset of the current row
 #pragma unroll
   for (int k = 0; k < RW; ++k) n2p[k] = (p2 - W)[dq[k + 1]];
 #pragma unroll
@@ -632,7 +665,7 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
 
   for (int row = r0; row < r1; ++row) {
     if (row + 1 < nyp) {
-      load_window(row + 1, px + rowX, prd + W, xp);
+      load_window(row + 1, sx + rowB, prd + W, pmk ? pmk + W : nullptr, xp);
     } else {
 #pragma unroll
       for (int q = 0; q < RW + 2; ++q) xp[q] = zero2;
@@ -658,17 +691,16 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
     for (int k = 0; k < RW; ++k) {
       const int q = k + 1;
       if (TAIL && (c0w + k >= W || c0w + k < 0)) continue;
-      const i64 o = (i64)k * Bp;
       if (MODE == M_JACOBI) {
         // unit form: bu = b / s_b; XFROMB: the window holds x1 = omega_in rd0 bu, so bu = x1 d0 / omega_in
         v2f braw = zero2, res;
         if (XFROMB) {
           res = xc[q] * (d0[k] * inv_omega_in);
+          if (DOT) braw = res * sb;
         } else {
-          braw = ld2(pb + o, lb);
+          braw = bld(rb, offq[q], sx);
           res = braw * ib;
         }
-        if (XFROMB && dot) braw = res * sb;
         res -= d0[k] * xc[q];
         res -= e1[k + 1] * xc[q + 1];
         res -= e1[k] * xc[q - 1];
@@ -678,9 +710,9 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
           res -= d3c[k] * xp[q - 1];
           res -= d3p[k + 1] * xm[q + 1];
         }
-        const v2f xo = xc[q] + (omega * prd[dq[k + 1]]) * res;
-        st2(po + o, lb, xo);
-        if (dot) {
+        const v2f xo = xc[q] + (omega * prd[dq[q]]) * res;
+        bst(ro, offq[q], sx, xo);
+        if (DOT) {
           const v2f pr = braw * xo;
           s0 += (double)pr.x;
           s1 += (double)pr.y;
@@ -695,9 +727,9 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
           acc += d3c[k] * xp[q - 1];
           acc += d3p[k + 1] * xm[q + 1];
         }
-        const v2f res = ld2(pb + o, lb) - sb * acc;
+        const v2f res = bld(rb, offq[q], sx) - sb * acc;
         if (FUSE == F_RESTRICT) resrow[k] = res;
-        else st2(po + o, lb, res);
+        else bst(ro, offq[q], sx, res);
       }
     }
     if (FUSE == F_RESTRICT) {
@@ -743,14 +775,13 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) d3p[k] = d3c[k];
     p0 += W; p1 += W; p2 += W; p3 += W; prd += W;
-    px += rowX;
-    if (pb) pb += rowX;
-    if (po) po += rowX;
+    if (FUSE == F_PROLONG) pmk += W;
+    sx += rowB;
   }
 }
 
-template <int MODE, int FUSE, int ND, bool XFROMB, int RW, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void dia_strip2_kernel(Level L, const double* __restrict__ scale,
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool DOT>
+__global__ __launch_bounds__(256) void dia_strip2_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ bvec,
                                                           float* __restrict__ out, float omega, float omega_in, Extra ex,
                                                           double* __restrict__ part, int Bp, int ncb, int TR) {
@@ -786,14 +817,14 @@ __global__ __launch_bounds__(256, MINW) void dia_strip2_kernel(Level L, const do
   const float* __restrict__ src = XFROMB ? bvec : xin;
   double s0 = 0.0, s1 = 0.0;
   if (active) {
-    if (c0w + RW + 1 > L.W || c0w < 0)
-      strip2_body<MODE, FUSE, ND, XFROMB, RW, true>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
-                                                    part != nullptr, s0, s1);
+    if (c0w + RW + 1 > L.W || c0w < 1)    // strips that touch the left or right edge: clamped window columns
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, true, DOT>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
+                                                         s0, s1);
     else
-      strip2_body<MODE, FUSE, ND, XFROMB, RW, false>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
-                                                     part != nullptr, s0, s1);
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, false, DOT>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0,
+                                                          r1, s0, s1);
   }
-  if (part) {
+  if (DOT) {
     const double t0 = block_sum_per_sample(s0, Bp, lds);
     const double t1 = block_sum_per_sample(s1, Bp, lds);
     if (wave == 0) {
@@ -873,7 +904,19 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 // no diagonal shift: the two-samples-per-lane kernels apply (DIFFHE_STRIP2=0 switches them off: A/B runs)
 inline bool strip2_ok(const Level& L, int Bv, int Bp) {
   static const int on = getenv("DIFFHE_STRIP2") ? atoi(getenv("DIFFHE_STRIP2")) : 1;
-  return on && Bv == 1 && L.v32 && L.rd32 && !L.shift && Bp % (2 * kWave) == 0;
+  return on && Bv == 1 && L.v32 && L.rd32 && L.mk32 && !L.shift && Bp % (2 * kWave) == 0;
+}
+// the kernels address their tile (`rows` fine rows + the window's two halo rows) with 32-bit byte offsets
+inline bool strip2_tile_fits(const Level& L, int Bp, int rows) { return 4LL * (rows + 3) * L.W * Bp < (1LL << 31); }
+// geometry for the two-samples-per-lane kernels if they apply to this level (and its tiles fit), else the usual one
+template <typename TV>
+inline bool strip2_pick(const Level& L, int Bv, int Bp, int rw, StripGeom* g) {
+  if (sizeof(TV) == 4 && strip2_ok(L, Bv, Bp)) {
+    *g = strip_geom(L, Bp, rw, 2);
+    if (!g->use || strip2_tile_fits(L, Bp, g->TR)) return g->use;
+  }
+  *g = strip_geom(L, Bp, rw, 1);
+  return false;
 }
 
 template <int MODE, bool XFROMB, int FUSE, int RW>
@@ -884,10 +927,14 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
   if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * 4.0 + (FUSE == F_PROLONG ? 1.0 : 0.0);
   else bpn = 8.0 + (FUSE == F_RESTRICT ? 1.0 : 4.0);
   diffhe::account(bpn * (double)L.n * Bp);
-#define STRIP2(ND_)                                                                                                 \
-  hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW>), grid, dim3(256), 0, st, L, scale, xin, bvec, out, \
+#define STRIP2(ND_, DOT_)                                                                                                 \
+  hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW, DOT_>), grid, dim3(256), 0, st, L, scale, xin, bvec, out, \
                      (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
-  if (L.nd == 3) STRIP2(3); else STRIP2(4);
+  if (MODE == M_JACOBI && part) {   // the sweep that leaves the partials of rhs . x (the CG's r.z)
+    if (L.nd == 3) STRIP2(3, (MODE == M_JACOBI)); else STRIP2(4, (MODE == M_JACOBI));
+  } else {
+    if (L.nd == 3) STRIP2(3, false); else STRIP2(4, false);
+  }
 #undef STRIP2
 }
 
@@ -1394,8 +1441,8 @@ template <typename TV>
 int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, double omega, double* part,
               hipStream_t st) {
   const Level& L = H.lev[l];
-  const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
-  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
+  StripGeom g;
+  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
   if (g.use && xin) {
     if (l == 0) kp_begin(KP_SWEEP, st);
     if (two)
@@ -1416,8 +1463,8 @@ template <typename TV>
 int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double w0, double w1, double* part,
                      TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
-  const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
-  const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
+  StripGeom g;
+  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
   if (g.use) {
     if (l == 0) kp_begin(KP_FIRST2, st);
     if (two)
@@ -1639,15 +1686,19 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
         // residual + full-weighting restriction in one pass: the residual is never stored
         constexpr int CW = kRestrictCols;
-        const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+        bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
         StripGeom g{true, 0, 0, 0};
         g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
-        const int gy = H.Bp / (two ? 2 * kWave : kWave);
-        int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
-        if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
-        if (nrc < 1) nrc = 1;
-        g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
-        g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+        for (int pass = 0; pass < 2; ++pass) {
+          const int gy = H.Bp / (two ? 2 * kWave : kWave);
+          int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
+          if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+          if (nrc < 1) nrc = 1;
+          g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+          g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+          if (!two || strip2_tile_fits(L, H.Bp, 2 * g.TR + 1)) break;
+          two = false;                         // tiles beyond 32-bit offsets: the one-sample-per-lane kernel
+        }
         Extra ex{};
         ex.cW = C.W;
         ex.bc = C.bc;
@@ -1672,8 +1723,8 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = cur[l];
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
-    const bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
-    const StripGeom g = strip_geom(L, H.Bp, strip_cols<TV>(), two ? 2 : 1);
+    StripGeom g;
+    const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
     if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
@@ -1782,7 +1833,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32; L.mk32 = s.mask32;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
@@ -2167,7 +2218,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   Level L{};   // inv, shift: none
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
-  L.rd32 = nullptr;
+  L.rd32 = nullptr; L.mk32 = nullptr;
   const StripGeom g = strip_geom(L, Bp);
   if (g.use && (!sub || sub_B == 1)) {
     Extra ex{};

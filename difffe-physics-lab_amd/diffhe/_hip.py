@@ -19,7 +19,7 @@ ABI_VERSION = 6     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding wa
 class MgLevel(C.Structure):
     """struct diffhe_mg_level (include/diffhe_hip.h)."""
     _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P), ("vals32", _P),
-                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P)]
+                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P), ("mask32", _P)]
 
 
 _LV = C.POINTER(MgLevel)

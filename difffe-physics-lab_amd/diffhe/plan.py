@@ -392,6 +392,12 @@ class LatticeLevel:
             self._lumped = torch.from_numpy(m).to(self._device)
         return self._lumped
 
+    def mask32(self) -> torch.Tensor:
+        """(n) fp32: 0 on Dirichlet rows, 1 elsewhere (what the two-samples-per-lane strip kernels scalar-load)."""
+        if getattr(self, "_mask32", None) is None:
+            self._mask32 = (1 - self.is_bc.to(torch.float32)).contiguous()
+        return self._mask32
+
     def zero_g(self):
         """Dirichlet values of a coarse level: corrections vanish there."""
         if self._zero_g is None:

@@ -293,6 +293,7 @@ class _Engine:
             arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
             arr[i].shift = shift[i].data_ptr() if shift is not None else None
             arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
+            arr[i].mask32 = lev.mask32().data_ptr() if arr[i].rdiag32 else None
         return arr
 
     def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None):

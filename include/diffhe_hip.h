@@ -241,8 +241,9 @@ typedef struct diffhe_mg_level {
   const float* rdiag32;        /* optional (n), Bv == 1 only (ABI v6): fp32 reciprocal of the main diagonal vals[0].  Given
                                   together with vals32 (here (nd, n): fp32 copy of the SHARED values) it lets the
                                   fp32-stored V-cycle run its two-samples-per-lane strip kernels (packed fp32
-                                  arithmetic, no division); needs Bp % 128 == 0 and no shift; NULL = the fp64-in-registers
-                                  kernels */
+                                  arithmetic, no division); needs mask32, Bp % 128 == 0 and no shift; NULL = the
+                                  fp64-in-registers kernels */
+  const float* mask32;         /* with rdiag32: (n) 0.0f on Dirichlet rows, 1.0f elsewhere (is_bc as scalar-loadable floats) */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the

@@ -295,3 +295,58 @@ def test_shared_field_gradient_is_the_sum_of_the_per_sample_gradients(mesh_kind)
         ref += dk
     if B <= 5:
         assert rel_err(gk.cpu().numpy(), ref) < RTOL_GRAD
+
+
+# ---- two-samples-per-lane strip kernels (fp32 V-cycle, batch-shared matrix, batch a multiple of 128) ---------------------
+def _skewed(nx, ny, seed=0):
+    """rectangle connectivity with jittered interior nodes: obtuse triangles, 4 stored diagonals, lattice path."""
+    base = FEMesh.rectangle(nx, ny, x_range=(0.0, 1.3), y_range=(0.0, 0.9), bc_value=0.2)
+    rng = np.random.default_rng(seed)
+    nodes = base.nodes.numpy().copy().reshape(ny + 1, nx + 1, 2)
+    nodes[1:-1, 1:-1] += rng.uniform(-0.25, 0.25, size=(ny - 1, nx - 1, 2)) * np.array([1.3 / nx, 0.9 / ny])
+    return FEMesh(nodes=torch.from_numpy(nodes.reshape(-1, 2)), elements=base.elements, dirichlet_nodes=base.dirichlet_nodes)
+
+
+def _partly_neumann(nx, ny):
+    base = FEMesh.rectangle(nx, ny)
+    W = nx + 1
+    bc = {i * W: 0.5 for i in range(ny + 1)}
+    bc.update({j: 0.0 for j in range(W)})                        # left and bottom edges Dirichlet, the rest Neumann
+    return FEMesh(nodes=base.nodes, elements=base.elements, dirichlet_nodes=dict(sorted(bc.items())))
+
+
+@pytest.mark.parametrize("name,mesh,kind", [
+    ("uniform 256^2, scalar kappa per sample", FEMesh.rectangle(256, 256), "sample"),
+    ("odd sizes 333 x 207 (edge strips), non-zero Dirichlet data", FEMesh.rectangle(333, 207, bc_value=0.7), "sample"),
+    ("skewed lattice (4 diagonals)", _skewed(272, 232), "sample"),
+    ("partly Neumann boundary (assembled scalar-kappa operator, shared)", _partly_neumann(240, 224), "scalar"),
+    ("one per-element field shared by the batch", FEMesh.rectangle(288, 264), "field"),
+])
+def test_two_samples_per_lane_kernels_agree_with_the_one_sample_kernels_and_the_oracle(name, mesh, kind):
+    """B = 128 puts the fp32 V-cycle of a batch-shared matrix on dia_strip2_kernel (packed fp32 arithmetic, 8 B per
+    lane); mg={'strip2': 0} keeps the fp64-in-registers kernels.  Both are preconditioners of the same fp64 CG: the
+    solutions agree far inside the tolerance, the iteration counts do not move, and the result matches the oracle."""
+    B, n, m = 128, mesh.n_nodes, mesh.n_elements
+    gen = torch.Generator().manual_seed(77)
+    if kind == "sample":
+        kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    elif kind == "scalar":
+        kappa = torch.tensor(1.37, dtype=T64)
+    else:
+        kappa = torch.exp(0.3 * torch.randn(m, generator=gen, dtype=T64))
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    new = _run(mesh, kappa, f)
+    old = _run(mesh, kappa, f, mg=dict(strip2=0))
+    assert new[3].path == "lattice-mgpcg" and new[3].not_converged == 0 and old[3].not_converged == 0
+    assert abs(new[3].iterations - old[3].iterations) <= 1 and abs(new[3].adj_iterations - old[3].adj_iterations) <= 1
+    for a, b in zip(new[:3], old[:3]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-11, name
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B - 1):
+        kb = float(kappa[b]) if kind == "sample" else kappa.numpy()
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=1)
+        assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U, name
+        assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD, name
+        if kind == "sample":
+            assert abs(float(new[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum()), name
