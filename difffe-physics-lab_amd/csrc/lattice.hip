@@ -570,7 +570,7 @@ __device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, v2f 
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
 }
 
-template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool TAIL, bool DOT>
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool TAIL, bool DOT, bool BST>
 __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, const float* __restrict__ src,
                                             const float* __restrict__ bvec, float* __restrict__ out, float omega,
                                             float omega_in, const Extra& ex, int Bp, unsigned lb, int c0w, int r0,
@@ -603,6 +603,7 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
   const rsrc_t rx = make_rsrc(src + tile0);
   const rsrc_t rb = make_rsrc(bvec ? bvec + tile0 : nullptr);
   const rsrc_t ro = make_rsrc((out && FUSE != F_RESTRICT) ? out + tile0 : nullptr);
+  float* __restrict__ po = (out && FUSE != F_RESTRICT) ? out + tile0 + (i64)W * Bp : nullptr;   // row r0, column c0w - 1
   const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;                   // bytes per grid row
   const float inv_omega_in = XFROMB ? 1.0f / omega_in : 0.0f;
   const float* __restrict__ aux = (const float*)ex.a0;
@@ -711,7 +712,8 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
           res -= d3p[k + 1] * xm[q + 1];
         }
         const v2f xo = xc[q] + (omega * prd[dq[q]]) * res;
-        bst(ro, offq[q], sx, xo);
+        if (BST) bst(ro, offq[q], sx, xo);
+        else *(v2f*)((char*)po + offq[q]) = xo;
         if (DOT) {
           const v2f pr = braw * xo;
           s0 += (double)pr.x;
@@ -729,7 +731,8 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
         }
         const v2f res = bld(rb, offq[q], sx) - sb * acc;
         if (FUSE == F_RESTRICT) resrow[k] = res;
-        else bst(ro, offq[q], sx, res);
+        else if (BST) bst(ro, offq[q], sx, res);
+        else *(v2f*)((char*)po + offq[q]) = res;
       }
     }
     if (FUSE == F_RESTRICT) {
@@ -777,10 +780,11 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
     p0 += W; p1 += W; p2 += W; p3 += W; prd += W;
     if (FUSE == F_PROLONG) pmk += W;
     sx += rowB;
+    if (!BST && po) po += (i64)W * Bp;
   }
 }
 
-template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool DOT>
+template <int MODE, int FUSE, int ND, bool XFROMB, int RW, bool DOT, bool BST>
 __global__ __launch_bounds__(256) void dia_strip2_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ bvec,
                                                           float* __restrict__ out, float omega, float omega_in, Extra ex,
@@ -818,10 +822,10 @@ __global__ __launch_bounds__(256) void dia_strip2_kernel(Level L, const double* 
   double s0 = 0.0, s1 = 0.0;
   if (active) {
     if (c0w + RW + 1 > L.W || c0w < 1)    // strips that touch the left or right edge: clamped window columns
-      strip2_body<MODE, FUSE, ND, XFROMB, RW, true, DOT>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, true, DOT, BST>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0, r1,
                                                          s0, s1);
     else
-      strip2_body<MODE, FUSE, ND, XFROMB, RW, false, DOT>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0,
+      strip2_body<MODE, FUSE, ND, XFROMB, RW, false, DOT, BST>(L, ib, sb, src, bvec, out, omega, omega_in, ex, Bp, lb, c0w, r0,
                                                           r1, s0, s1);
   }
   if (DOT) {
@@ -927,14 +931,20 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
   if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * 4.0 + (FUSE == F_PROLONG ? 1.0 : 0.0);
   else bpn = 8.0 + (FUSE == F_RESTRICT ? 1.0 : 4.0);
   diffhe::account(bpn * (double)L.n * Bp);
-#define STRIP2(ND_, DOT_)                                                                                                 \
-  hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW, DOT_>), grid, dim3(256), 0, st, L, scale, xin, bvec, out, \
-                     (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
+  // development knobs (read per launch): DIFFHE_S2_BST=1 buffer stores instead of flat ones; DIFFHE_S2_LDS=<bytes> of
+  // dynamic LDS per block, which caps the blocks resident per CU (160 KB / bytes)
+  const int bstore = getenv("DIFFHE_S2_BST") ? atoi(getenv("DIFFHE_S2_BST")) : 0;
+  const unsigned dyn_lds = getenv("DIFFHE_S2_LDS") ? (unsigned)atoi(getenv("DIFFHE_S2_LDS")) : 0u;
+#define STRIP2(ND_, DOT_, BST_)                                                                                            \
+  hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW, DOT_, BST_>), grid, dim3(256), dyn_lds, st, L, scale, xin, \
+                     bvec, out, (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
+#define STRIP2B(ND_, DOT_) do { if (bstore && FUSE != F_RESTRICT) STRIP2(ND_, DOT_, (FUSE != F_RESTRICT)); else STRIP2(ND_, DOT_, false); } while (0)
   if (MODE == M_JACOBI && part) {   // the sweep that leaves the partials of rhs . x (the CG's r.z)
-    if (L.nd == 3) STRIP2(3, (MODE == M_JACOBI)); else STRIP2(4, (MODE == M_JACOBI));
+    if (L.nd == 3) STRIP2B(3, (MODE == M_JACOBI)); else STRIP2B(4, (MODE == M_JACOBI));
   } else {
-    if (L.nd == 3) STRIP2(3, false); else STRIP2(4, false);
+    if (L.nd == 3) STRIP2B(3, false); else STRIP2B(4, false);
   }
+#undef STRIP2B
 #undef STRIP2
 }
 

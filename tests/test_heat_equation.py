@@ -225,7 +225,7 @@ def test_factored_reaction_on_strip_kernels_matches_oracle(kmode):
     u = solver(ft, load=lt)
     (u ** 2).sum().backward()
     assert solver.last_info.path == "lattice-mgpcg" and solver.last_info.not_converged == 0
-    assert get_plan(mesh, torch.device("cuda", 0))._shift_cache["c"] == c          # the factored form was used
+    assert c in get_plan(mesh, torch.device("cuda", 0))._shift_cache                # the factored form was used
     dk_all = 0.0
     for b in (0, B // 2, B - 1):
         kb = float(kap) if kmode == "scalar" else kap[b]
