@@ -887,8 +887,10 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
     if (Bv != 1) bpn += L.nd * (m32 ? 4.0 : 8.0);
     diffhe::account(bpn * (double)L.n * Bp);
   }
+  // development knob: DIFFHE_S1_LDS=<bytes> of dynamic LDS per block caps the blocks resident per CU (160 KB / bytes)
+  const unsigned dyn_lds = getenv("DIFFHE_S1_LDS") ? (unsigned)atoi(getenv("DIFFHE_S1_LDS")) : 0u;
 #define STRIP(ND_, SH_, TM_)                                                                                       \
-  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW, MINW>), grid, dim3(256), 0, st, L,   \
+  hipLaunchKernelGGL((dia_strip_kernel<TV, TA, TM_, MODE, FUSE, ND_, SH_, XFROMB, RW, MINW>), grid, dim3(256), dyn_lds, st, L,   \
                      scale, xin, bvec, out, omega, omega_in, ex, part, Bp, g.ncb, g.TR)
 #define STRIP_SHIFT(ND_)                                                                                           \
   hipLaunchKernelGGL((dia_strip_shift_kernel<TV, TA, MODE, FUSE, ND_, XFROMB, RW, MINW>), grid, dim3(256), 0, st, L, scale, \
@@ -934,7 +936,7 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
   // development knobs (read per launch): DIFFHE_S2_BST=1 buffer stores instead of flat ones; DIFFHE_S2_LDS=<bytes> of
   // dynamic LDS per block, which caps the blocks resident per CU (160 KB / bytes)
   const int bstore = getenv("DIFFHE_S2_BST") ? atoi(getenv("DIFFHE_S2_BST")) : 0;
-  const unsigned dyn_lds = getenv("DIFFHE_S2_LDS") ? (unsigned)atoi(getenv("DIFFHE_S2_LDS")) : 0u;
+  const unsigned dyn_lds = getenv("DIFFHE_S2_LDS") ? (unsigned)atoi(getenv("DIFFHE_S2_LDS")) : 40000u;
 #define STRIP2(ND_, DOT_, BST_)                                                                                            \
   hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW, DOT_, BST_>), grid, dim3(256), dyn_lds, st, L, scale, xin, \
                      bvec, out, (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
@@ -1451,8 +1453,12 @@ template <typename TV>
 int op_jacobi(const Hier& H, int l, const TV* rhs, const TV* xin, TV* xout, double omega, double* part,
               hipStream_t st) {
   const Level& L = H.lev[l];
+  // the plain sweep runs at the HBM rate of its real traffic either way (0.69 ms one sample per lane, 0.70-0.72 two):
+  // it keeps the one-sample kernel; DIFFHE_S2_SWEEP=1 switches it over too
+  static const int sweep2 = getenv("DIFFHE_S2_SWEEP") ? atoi(getenv("DIFFHE_S2_SWEEP")) : 0;
   StripGeom g;
-  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
+  const bool two = sweep2 ? strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g)
+                          : (g = strip_geom(L, H.Bp, strip_cols<TV>()), false);
   if (g.use && xin) {
     if (l == 0) kp_begin(KP_SWEEP, st);
     if (two)
