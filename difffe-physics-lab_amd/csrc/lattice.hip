@@ -908,6 +908,10 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 
 // fp32 V-cycle, batch-shared matrix with fp32 coefficient copies and reciprocal diagonal, batch a multiple of 128,
 // no diagonal shift: the two-samples-per-lane kernels apply (DIFFHE_STRIP2=0 switches them off: A/B runs)
+inline int strip2_cols() {   // development knob: columns per wave of the two-samples-per-lane kernels (4 or 8)
+  static const int rw = getenv("DIFFHE_S2_RW") ? atoi(getenv("DIFFHE_S2_RW")) : 4;
+  return rw == 8 ? 8 : 4;
+}
 inline bool strip2_ok(const Level& L, int Bv, int Bp) {
   static const int on = getenv("DIFFHE_STRIP2") ? atoi(getenv("DIFFHE_STRIP2")) : 1;
   return on && Bv == 1 && L.v32 && L.rd32 && L.mk32 && !L.shift && Bp % (2 * kWave) == 0;
@@ -1480,10 +1484,13 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
                      TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
   StripGeom g;
-  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
+  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip2_cols(), &g) || (g = strip_geom(L, H.Bp, strip_cols<TV>()), false);
   if (g.use) {
     if (l == 0) kp_begin(KP_FIRST2, st);
-    if (two)
+    if (two && strip2_cols() == 8)
+      launch_strip2<M_JACOBI, true, F_NONE, 8>(L, H.scale, (const float*)nullptr, (const float*)rhs, (float*)xa, w1, w0,
+                                               part, H.Bp, g, st);
+    else if (two)
       launch_strip2<M_JACOBI, true, F_NONE, 4>(L, H.scale, (const float*)nullptr, (const float*)rhs, (float*)xa, w1, w0,
                                                part, H.Bp, g, st);
     else
@@ -1703,9 +1710,11 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         // residual + full-weighting restriction in one pass: the residual is never stored
         constexpr int CW = kRestrictCols;
         bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+        int cw = CW;
         StripGeom g{true, 0, 0, 0};
-        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
         for (int pass = 0; pass < 2; ++pass) {
+          cw = (two && strip2_cols() == 8) ? 2 * CW : CW;   // coarse columns per wave
+          g.ncb = (C.W + 4 * cw - 1) / (4 * cw);
           const int gy = H.Bp / (two ? 2 * kWave : kWave);
           int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
           if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
@@ -1719,7 +1728,10 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         ex.cW = C.W;
         ex.bc = C.bc;
         if (l == 0) kp_begin(KP_RESTRICT, st);
-        if (two)
+        if (two && cw == 2 * CW)
+          launch_strip2<M_RESID, false, F_RESTRICT, 4 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
+                                                                (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
+        else if (two)
           launch_strip2<M_RESID, false, F_RESTRICT, 2 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
                                                                 (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
         else
@@ -1740,13 +1752,16 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
     StripGeom g;
-    const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
+    const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip2_cols(), &g) || (g = strip_geom(L, H.Bp, strip_cols<TV>()), false);
     if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
       if (l == 0) kp_begin(KP_PROLONG, st);
-      if (two)
+      if (two && strip2_cols() == 8)
+        launch_strip2<M_JACOBI, false, F_PROLONG, 8>(L, H.scale, (const float*)a, (const float*)rhs[l], (float*)b2,
+                                                     H.omega[H.nu - 1], 0.0, lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
+      else if (two)
         launch_strip2<M_JACOBI, false, F_PROLONG, 4>(L, H.scale, (const float*)a, (const float*)rhs[l], (float*)b2,
                                                      H.omega[H.nu - 1], 0.0, lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
       else
