@@ -908,10 +908,6 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 
 // fp32 V-cycle, batch-shared matrix with fp32 coefficient copies and reciprocal diagonal, batch a multiple of 128,
 // no diagonal shift: the two-samples-per-lane kernels apply (DIFFHE_STRIP2=0 switches them off: A/B runs)
-inline int strip2_cols() {   // development knob: columns per wave of the two-samples-per-lane kernels (4 or 8)
-  static const int rw = getenv("DIFFHE_S2_RW") ? atoi(getenv("DIFFHE_S2_RW")) : 4;
-  return rw == 8 ? 8 : 4;
-}
 inline bool strip2_ok(const Level& L, int Bv, int Bp) {
   static const int on = getenv("DIFFHE_STRIP2") ? atoi(getenv("DIFFHE_STRIP2")) : 1;
   return on && Bv == 1 && L.v32 && L.rd32 && L.mk32 && !L.shift && Bp % (2 * kWave) == 0;
@@ -937,14 +933,14 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
   if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * 4.0 + (FUSE == F_PROLONG ? 1.0 : 0.0);
   else bpn = 8.0 + (FUSE == F_RESTRICT ? 1.0 : 4.0);
   diffhe::account(bpn * (double)L.n * Bp);
-  // development knobs (read per launch): DIFFHE_S2_BST=1 buffer stores instead of flat ones; DIFFHE_S2_LDS=<bytes> of
-  // dynamic LDS per block, which caps the blocks resident per CU (160 KB / bytes)
-  const int bstore = getenv("DIFFHE_S2_BST") ? atoi(getenv("DIFFHE_S2_BST")) : 0;
-  const unsigned dyn_lds = getenv("DIFFHE_S2_LDS") ? (unsigned)atoi(getenv("DIFFHE_S2_LDS")) : 40000u;
+  // 40 000 B of dynamic LDS per block cap the residency at 4 blocks (16 waves) per CU: measured best for these kernels
+  // (sweep over 3 .. 7 blocks per CU on one box, gpurun_out/r3d: first two sweeps 0.506 / prolongation 0.803 / restriction
+  // 0.582 ms at 4 against 0.514-0.523 / 0.815-0.818 / 0.589-0.590 unrestricted); DIFFHE_S2_LDS=<bytes> overrides
+  static const unsigned dyn_lds = getenv("DIFFHE_S2_LDS") ? (unsigned)atoi(getenv("DIFFHE_S2_LDS")) : 40000u;
 #define STRIP2(ND_, DOT_, BST_)                                                                                            \
   hipLaunchKernelGGL((dia_strip2_kernel<MODE, FUSE, ND_, XFROMB, RW, DOT_, BST_>), grid, dim3(256), dyn_lds, st, L, scale, xin, \
                      bvec, out, (float)omega, (float)omega_in, ex, part, Bp, g.ncb, g.TR)
-#define STRIP2B(ND_, DOT_) do { if (bstore && FUSE != F_RESTRICT) STRIP2(ND_, DOT_, (FUSE != F_RESTRICT)); else STRIP2(ND_, DOT_, false); } while (0)
+#define STRIP2B(ND_, DOT_) STRIP2(ND_, DOT_, false)
   if (MODE == M_JACOBI && part) {   // the sweep that leaves the partials of rhs . x (the CG's r.z)
     if (L.nd == 3) STRIP2B(3, (MODE == M_JACOBI)); else STRIP2B(4, (MODE == M_JACOBI));
   } else {
@@ -1484,13 +1480,10 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
                      TV** result, hipStream_t st) {
   const Level& L = H.lev[l];
   StripGeom g;
-  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip2_cols(), &g) || (g = strip_geom(L, H.Bp, strip_cols<TV>()), false);
+  const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
   if (g.use) {
     if (l == 0) kp_begin(KP_FIRST2, st);
-    if (two && strip2_cols() == 8)
-      launch_strip2<M_JACOBI, true, F_NONE, 8>(L, H.scale, (const float*)nullptr, (const float*)rhs, (float*)xa, w1, w0,
-                                               part, H.Bp, g, st);
-    else if (two)
+    if (two)
       launch_strip2<M_JACOBI, true, F_NONE, 4>(L, H.scale, (const float*)nullptr, (const float*)rhs, (float*)xa, w1, w0,
                                                part, H.Bp, g, st);
     else
@@ -1710,11 +1703,9 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         // residual + full-weighting restriction in one pass: the residual is never stored
         constexpr int CW = kRestrictCols;
         bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
-        int cw = CW;
         StripGeom g{true, 0, 0, 0};
+        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
         for (int pass = 0; pass < 2; ++pass) {
-          cw = (two && strip2_cols() == 8) ? 2 * CW : CW;   // coarse columns per wave
-          g.ncb = (C.W + 4 * cw - 1) / (4 * cw);
           const int gy = H.Bp / (two ? 2 * kWave : kWave);
           int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
           if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
@@ -1728,10 +1719,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         ex.cW = C.W;
         ex.bc = C.bc;
         if (l == 0) kp_begin(KP_RESTRICT, st);
-        if (two && cw == 2 * CW)
-          launch_strip2<M_RESID, false, F_RESTRICT, 4 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
-                                                                (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
-        else if (two)
+        if (two)
           launch_strip2<M_RESID, false, F_RESTRICT, 2 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
                                                                 (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
         else
@@ -1752,16 +1740,13 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
     int s0 = 0;
     StripGeom g;
-    const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip2_cols(), &g) || (g = strip_geom(L, H.Bp, strip_cols<TV>()), false);
+    const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
     if (g.use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {  // prolongate + correct + first post-sweep in one pass
       const bool lastsweep = (l == l0 && H.nu == 1);
       Extra ex{};
       ex.a0 = cur[l + 1]; ex.cW = C.W; ex.bc = L.bc;
       if (l == 0) kp_begin(KP_PROLONG, st);
-      if (two && strip2_cols() == 8)
-        launch_strip2<M_JACOBI, false, F_PROLONG, 8>(L, H.scale, (const float*)a, (const float*)rhs[l], (float*)b2,
-                                                     H.omega[H.nu - 1], 0.0, lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
-      else if (two)
+      if (two)
         launch_strip2<M_JACOBI, false, F_PROLONG, 4>(L, H.scale, (const float*)a, (const float*)rhs[l], (float*)b2,
                                                      H.omega[H.nu - 1], 0.0, lastsweep ? rz_part : nullptr, H.Bp, g, st, ex);
       else
