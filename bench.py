@@ -156,7 +156,10 @@ def main():
             return (0.5 + 1.5 * torch.rand(B, generator=g_, dtype=torch.float64)).to(dev).requires_grad_(True)
         g_ = torch.Generator(device=dev).manual_seed(seed)
         shape = (B, m) if kind == "element" else (m,)
-        return torch.exp(0.3 * torch.randn(*shape, generator=g_, dtype=torch.float64, device=dev)).requires_grad_(True)
+        k_ = torch.exp(0.3 * torch.randn(*shape, generator=g_, dtype=torch.float64, device=dev))
+        if kind == "element" and node:      # layout='node': per-sample fields are kept element-major (m, B), like f and u
+            k_ = k_.t().contiguous()
+        return k_.requires_grad_(True)
 
     # seeds of SURVEY 8(d): 4096 (+ rank) for the scalars, 2025 (+ rank) for per-sample fields; a SHARED field is the
     # same on every rank (seed 2025)
@@ -773,8 +776,11 @@ def cpu_baseline_and_parity(args, np, torch, mesh, kappa, kgrad, u, B, N, node):
     # sample per worker process on `workers` cores at once (SuperLU itself is single-threaded)
     workers = max(1, min(cores, 16, B))
     idx = sorted({int(round(i * (B - 1) / max(workers - 1, 1))) for i in range(workers)})   # first ... last
-    kap = kappa.detach().cpu().numpy()
-    jobs = [(nodes, elements, bn, bv, (float(kap[b]) if args.kappa == "sample" else kap[b]), B, n) for b in idx]
+    kap = kappa.detach()
+    if args.kappa == "element" and node:
+        kap, kgrad = kap.t(), kgrad.t()              # (B, m) views of the element-major tensors
+    kap = kap.cpu().numpy() if args.kappa == "sample" else kap
+    jobs = [(nodes, elements, bn, bv, (float(kap[b]) if args.kappa == "sample" else kap[b].cpu().numpy()), B, n) for b in idx]
     if len(jobs) > 1:
         with mp.get_context("spawn").Pool(len(jobs)) as pool:
             res = pool.map(_oracle_sample, jobs)

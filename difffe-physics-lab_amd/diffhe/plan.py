@@ -392,6 +392,13 @@ class LatticeLevel:
             self._lumped = torch.from_numpy(m).to(self._device)
         return self._lumped
 
+    def k0ref(self) -> torch.Tensor:
+        """(9, m) unit-kappa element stiffness entries fl(t / den) with t and den in the reference's operation order
+        (solver.py:125-139): the batch-shared factors of the fast per-sample assembly."""
+        if getattr(self, "_k0ref", None) is None:
+            self._k0ref = (self.tnum / self.den.unsqueeze(0)).contiguous()
+        return self._k0ref
+
     def mask32(self) -> torch.Tensor:
         """(n) fp32: 0 on Dirichlet rows, 1 elsewhere (what the two-samples-per-lane strip kernels scalar-load)."""
         if getattr(self, "_mask32", None) is None:

@@ -87,6 +87,7 @@ class _Engine:
     def __init__(self, plan: SolvePlan, tol: float, max_iter: int, check_every: int, assembly: str):
         self.p = plan
         self.tol, self.max_iter, self.check_every, self.assembly = tol, max_iter, check_every, assembly
+        self.ref_order = False      # per-sample lattice matrices in the reference's exact operation order (operator="assembled")
         self.L = _hip.lib()
 
     # -- layout helpers -----------------------------------------------------------------
@@ -106,8 +107,23 @@ class _Engine:
                                                  _stream(p.device)), "diffhe_to_sample_major")
         return dst
 
+    def field_node_major(self, k, B, Bp, em):
+        """(m, Bp) per-sample kappa fields (padding samples = 1) from the API's (B, m) -- one transposing pass -- or from
+        an element-major (m, B) tensor (layout='node'): used as it is when B needs no padding."""
+        p = self.p
+        if em:
+            if Bp == B and k.is_contiguous():
+                return k
+            kp = torch.ones((p.m, Bp), dtype=torch.float64, device=p.device)
+            kp[:, :B] = k
+            return kp
+        kp = self.to_node_major(k.reshape(B, p.m).contiguous(), B, Bp, p.m)
+        if Bp > B:
+            kp[:, B:] = 1.0
+        return kp
+
     # -- general path ---------------------------------------------------------------------
-    def kappa_device(self, kappa, mode, B, Bp):
+    def kappa_device(self, kappa, mode, B, Bp, em=False):
         """-> (tensor, stride_e, stride_b, Bv) in the layout the kernels index."""
         p = self.p
         k = kappa.detach().to(p.device, torch.float64)
@@ -119,10 +135,7 @@ class _Engine:
             kp = torch.ones(Bp, dtype=torch.float64, device=p.device)
             kp[:B] = k.reshape(B)
             return kp, 0, 1, Bp
-        kp = self.to_node_major(k.reshape(B, p.m).contiguous(), B, Bp, p.m)
-        if Bp > B:
-            kp[:, B:] = 1.0
-        return kp, Bp, 1, Bp
+        return self.field_node_major(k, B, Bp, em), Bp, 1, Bp
 
     def assemble(self, kdev, kse, ksb, Bv):
         p, L = self.p, self.L
@@ -219,7 +232,7 @@ class _Engine:
         return x, int(st[0]), int(st[1]), relres
 
     # -- lattice path -----------------------------------------------------------------------
-    def lattice_assemble(self, kappa, mode, B, Bp, factor=True, n_levels=None):
+    def lattice_assemble(self, kappa, mode, B, Bp, factor=True, n_levels=None, em=False):
         """Per-level symmetric-diagonal operators.  -> (vals per level, Bv, scale, lift, lift_scale).
 
         One scalar kappa per sample is kept factored, K_b = kappa_b * K_1 (solver.py:88,139 are
@@ -247,9 +260,7 @@ class _Engine:
         elif mode == K_ELEM:
             kl, kse, ksb, Bv = k.reshape(p.m, 1).contiguous(), 1, 0, 1
         else:
-            kl = self.to_node_major(k.reshape(B, p.m).contiguous(), B, Bp, p.m)
-            if Bp > B:
-                kl[:, B:] = 1.0
+            kl = self.field_node_major(k, B, Bp, em)
             kse, ksb, Bv = Bp, 1, Bp
         vals, lift = [], None
         for li, lev in enumerate(p.levels[:n_levels] if n_levels else p.levels):
@@ -262,7 +273,18 @@ class _Engine:
                 kl = kc
             v = torch.empty((lev.nd, lev.n, Bv), dtype=torch.float64, device=p.device)
             lf = torch.empty((lev.n, Bv), dtype=torch.float64, device=p.device) if li == 0 else None
-            if li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
+            if li == 0 and kl is not None and Bv != 1 and not self.ref_order:
+                # one matrix per sample (a kappa field per sample), default: entries sum_e kappa_e * fl(t_e / den_e) with
+                # the batch-shared quotients precomputed in the reference's rounding -- ONE rounding away from the
+                # reference's fl(fl(kappa_e t_e) / den_e) per contribution (a cond * eps effect in u, like the factored
+                # form) instead of twelve IEEE fp64 divisions per node and sample (10.3 -> 3 ms at 1024^2 x 256);
+                # operator="assembled" keeps the bit-identical order below
+                _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0ref()), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
+                                                      _hip.ptr(lev.contrib), _hip.ptr(lev.cols),
+                                                      _hip.ptr(lev.store_slot), _hip.ptr(lev.is_bc), _hip.ptr(p.g),
+                                                      _hip.ptr(v), _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
+                           "diffhe_ell_assemble_rows(lattice, per-sample fields)")
+            elif li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
                 _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(lev.tnum), _hip.ptr(lev.den), _hip.ptr(kl), kse, ksb,
                                                           _hip.ptr(lev.ent_ptr), _hip.ptr(lev.contrib),
                                                           _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
@@ -427,6 +449,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         load = None
     plan: SolvePlan = solver._plan()
     eng = _Engine(plan, solver.tol, solver.max_iter, solver.check_every, solver.assembly)
+    eng.ref_order = solver.operator == "assembled"
     out_device = f.device
     batched = f.dim() == 2
     m, n = plan.m, plan.n
@@ -437,7 +460,11 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         load = load.t() if load is not None else None
     ctx.node_major = node_major
     B_f = f.shape[0] if batched else None
-    mode, B_k = _kappa_mode(kappa, m, B_f)
+    # layout='node': per-sample kappa fields may come element-major, (m, B), like f and u -- no transposing pass for
+    # kappa or its gradient either (a square (m, m) tensor is read that way)
+    kappa_em = bool(node_major and kappa.dim() == 2 and tuple(kappa.shape) == (m, B_f))
+    ctx.kappa_em = kappa_em
+    mode, B_k = (K_SAMPLE_ELEM, B_f) if kappa_em else _kappa_mode(kappa, m, B_f)
     B = B_f if B_f is not None else (B_k if B_k is not None else 1)
     if B_k is not None and B_k != B:
         raise ValueError(f"kappa batch {B_k} does not match f batch {B}")
@@ -556,7 +583,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # depend on c / kappa_b); per-sample matrices get it added to their diagonals
         didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1) and reaction == 0.0) else None
         vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_,
-                                                                 n_levels=None if didx is None else didx + 1)
+                                                                 n_levels=None if didx is None else didx + 1, em=kappa_em)
         shift = None
         if reaction and factored:
             shift = eng.reaction_shifts(reaction, len(vals))
@@ -601,7 +628,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
     else:
         plan.ensure_ell()
         Bp = padded_batch(B)
-        kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp)
+        kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp, em=kappa_em)
         vals, lift = eng.assemble(kdev, kse, ksb, Bv)
         if reaction:
             eng.add_reaction([vals], reaction, lattice=False)
@@ -735,7 +762,8 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
         dk_sample = dk_sum[:B] if need_k and dk_sum is not None else None
         dk_elem = None
         if need_k and mode == K_SAMPLE_ELEM:
-            dk_elem = eng.to_sample_major(dk_nm, B, Bp, m)          # (B, m)
+            # (B, m) like the API's kappa, or left element-major (m, B) when kappa came that way
+            dk_elem = (dk_nm if Bp == B else dk_nm[:, :B]) if ctx.kappa_em else eng.to_sample_major(dk_nm, B, Bp, m)
         df = None
         if need_f:
             df = eng.apply_M(lam, Bp, lattice=ctx.path.startswith("lattice-"))
