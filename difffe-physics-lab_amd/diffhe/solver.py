@@ -302,7 +302,23 @@ class _Engine:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def lattice_levels(self, vals, vals32=None, dense=None, shift=None, rdiag32=None):
+    def pack_cycle_coeffs(self, vals, Bv):
+        """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, bf16 off-diagonals) per level -- 8 instead of 12 B
+        of coefficients per node and sample (3 diagonals); every row sum of the fp64 matrix is kept."""
+        p, L = self.p, self.L
+        d32, o16 = [], []
+        for lev, v in zip(p.levels, vals):
+            one = (_hip.MgLevel * 1)()
+            one[0].nx, one[0].ny, one[0].nd, one[0].vals = lev.nx, lev.ny, lev.nd, v.data_ptr()
+            d = torch.empty((lev.n, Bv), dtype=torch.float32, device=p.device)
+            o = torch.empty((lev.nd - 1, lev.n, Bv), dtype=torch.int16, device=p.device)
+            _hip.check(L.diffhe_lattice_pack_bf16(one, Bv, _hip.ptr(d), _hip.ptr(o), _stream(p.device)),
+                       "diffhe_lattice_pack_bf16")
+            d32.append(d)
+            o16.append(o)
+        return d32, o16
+
+    def lattice_levels(self, vals, vals32=None, dense=None, shift=None, rdiag32=None, off16=None):
         """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
         level, whose solve becomes one dense product (diffhe_mg_level.dense_inv).  shift = per-level (n,) diagonal
         shifts of a factored operator (diffhe_mg_level.shift)."""
@@ -316,12 +332,14 @@ class _Engine:
             arr[i].shift = shift[i].data_ptr() if shift is not None else None
             arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
             arr[i].mask32 = lev.mask32().data_ptr() if arr[i].rdiag32 else None
+            arr[i].offdiag16 = off16[i].data_ptr() if off16 is not None and off16[i] is not None else None
         return arr
 
-    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None):
+    def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None,
+                    off16=None):
         """x0: (n, Bp) initial guess (warm start; left untouched) or None for the cold full-multigrid start."""
         p, L = self.p, self.L
-        arr = self.lattice_levels(vals, vals32, dense, shift, rdiag32)
+        arr = self.lattice_levels(vals, vals32, dense, shift, rdiag32, off16)
         nl = len(arr)
         warm = x0 is not None and x0.shape == (p.n, Bp)
         x = x0.clone() if warm else torch.empty((p.n, Bp), dtype=torch.float64, device=p.device)
@@ -596,8 +614,10 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # fp32-stored V-cycle: per-sample matrices are read from an fp32 copy of the coefficients; a batch-SHARED
         # matrix gets an fp32 copy and the reciprocal of its main diagonal (a few MB), which switch the strip levels
         # to the two-samples-per-lane kernels (packed fp32 arithmetic; batches that are multiples of 128, no shift)
-        vals32 = rdiag32 = None
-        if mg.get("fp32") and Bv != 1:
+        vals32 = rdiag32 = off16 = None
+        if mg.get("fp32") and Bv != 1 and mg.get("bf16", 1) and Bp > 1:
+            vals32, off16 = eng.pack_cycle_coeffs(vals, Bv)      # fp32 diagonal + bf16 off-diagonals (row sums kept)
+        elif mg.get("fp32") and Bv != 1:
             vals32 = [v.float() for v in vals]
         elif mg.get("fp32") and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
             vals32, rdiag32 = plan.shared_fp32(vals, cacheable=factored and kappa_free_unit)
@@ -610,8 +630,8 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         wkey = (Bp, mode, reaction)
         x, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, vals32, dense,
                                               x0=plan.warm_get(("u",) + wkey) if solver.warm_start else None, shift=shift,
-                                              rdiag32=rdiag32)
-        ctx.shift, ctx.wkey, ctx.rdiag32 = shift, wkey, rdiag32
+                                              rdiag32=rdiag32, off16=off16)
+        ctx.shift, ctx.wkey, ctx.rdiag32, ctx.off16 = shift, wkey, rdiag32, off16
         if solver.warm_start and not bad:
             plan.warm_put(("u",) + wkey, x)           # never written again: the next solve starts from a copy
         info.stop_rules = _rule_counts(eng.last_rule, B) if info.path != "lattice-direct" else {}
@@ -735,7 +755,7 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
             ws = ctx.solver.warm_start is True
             lam, its, bad, relres = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, ctx.mg, ctx.vals32, ctx.dense,
                                                     x0=plan.warm_get(("lambda",) + ctx.wkey) if ws else None,
-                                                    shift=ctx.shift, rdiag32=ctx.rdiag32)
+                                                    shift=ctx.shift, rdiag32=ctx.rdiag32, off16=ctx.off16)
             if ws and not bad:
                 plan.warm_put(("lambda",) + ctx.wkey, lam)
             info.adj_stop_rules = _rule_counts(eng.last_rule, B) if ctx.path != "lattice-direct" else {}

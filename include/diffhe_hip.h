@@ -244,6 +244,10 @@ typedef struct diffhe_mg_level {
                                   arithmetic, no division); needs mask32, Bp % 128 == 0 and no shift; NULL = the
                                   fp64-in-registers kernels */
   const float* mask32;         /* with rdiag32: (n) 0.0f on Dirichlet rows, 1.0f elsewhere (is_bc as scalar-loadable floats) */
+  const unsigned short* offdiag16; /* optional, Bv == Bp only (ABI v6): bf16 off-diagonals (nd - 1, n, Bv); vals32 is then
+                                  the (n, Bv) fp32 main diagonal adjusted to keep every row sum of `vals`
+                                  (diffhe_lattice_pack_bf16 produces both): 4 + 2 (nd - 1) instead of 4 nd bytes of
+                                  coefficients per node and sample in the fp32-stored V-cycle */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
@@ -326,6 +330,10 @@ int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* 
 int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, const double* x, const double* sub,
                                 int sub_B, const double* sub_scale, const unsigned char* mask, double* y, int Bp,
                                 void* stream);
+/* Compact coefficient copies of a per-sample matrix for the fp32-stored V-cycle (diffhe_mg_level.vals32 / offdiag16):
+ * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) bf16 (round to nearest even); the diagonal absorbs the rounding
+ * differences of its row's couplings, so the row sums -- what the smooth error modes see -- are those of `vals`. */
+int diffhe_lattice_pack_bf16(const diffhe_mg_level* level, int Bv, float* diag32, unsigned short* offdiag16, void* stream);
 /* kappa of the coarse triangulation, arrays (m, Bv); sx, sy in {1, 2} = coarsening factor per direction.
  * Full coarsening: mean of the 4 children of each coarse triangle; semi: mean over the 2 covered fine cells. */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
