@@ -2283,6 +2283,105 @@ extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const
   return diffhe::check_launch();
 }
 
+// dL/dkappa per element and sample on a lattice mesh (reverse of solver.py:137-140; Appendix A step 2):
+//   dk[e, b] = - sum_{p,q} lambda[node_p, b] k0[p*3+q, e] (u[node_q, b] + g[node_q])
+// Quad (r, c) = nodes a (r, c), b (r, c+1), c (r+1, c+1), d (r+1, c) carries T0 = [a, b, d] = element 2q and
+// T1 = [b, c, d] = element 2q + 1 (mesh.py:100-105).  A wave owns GW quad columns x 64 samples and marches down the quad
+// rows with a two-row window of lambda and u in registers: every nodal value is loaded once per wave (+ one halo
+// column) instead of once per incident element (6x), k0 arrives as scalar loads, dk leaves as 512 B rows.
+// 32 B per node and sample of algorithmic traffic (lambda, u, two dk): the element-loop kernel ran it at 1.2 TB/s.
+constexpr int kGradCols = 4;
+__global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny, const double* __restrict__ k0,
+                                                                  const double* __restrict__ lam,
+                                                                  const double* __restrict__ u,
+                                                                  const double* __restrict__ g, double* __restrict__ dk,
+                                                                  int Bp, int ncb, int TR) {
+  constexpr int GW = kGradCols;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * kWave + lane;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
+  const int c0 = (cb * 4 + wave) * GW;                 // first quad column
+  const int r0 = rc * TR;
+  const int r1 = (r0 + TR < ny) ? r0 + TR : ny;        // quad rows r0 .. r1 - 1
+  if (c0 >= nx || r0 >= r1) return;
+  const int W = nx + 1;
+  const i64 m = 2LL * nx * ny;
+  int dc[GW + 1];                                       // node columns c0 .. c0 + GW, clamped at the right edge
+#pragma unroll
+  for (int j = 0; j < GW + 1; ++j) dc[j] = (c0 + j < W) ? j : W - 1 - c0;
+  double la[GW + 1], ua[GW + 1], lbn[GW + 1], ubn[GW + 1];   // node rows r (a, b) and r + 1 (d, c)
+  const double* __restrict__ pl = lam + ((i64)r0 * W + c0) * Bp;
+  const double* __restrict__ pu = u + ((i64)r0 * W + c0) * Bp;
+  const double* __restrict__ pg = g ? g + (i64)r0 * W + c0 : nullptr;
+  const i64 rowX = (i64)W * Bp;
+#pragma unroll
+  for (int j = 0; j < GW + 1; ++j) {
+    la[j] = (pl + (i64)dc[j] * Bp)[lb];
+    ua[j] = (pu + (i64)dc[j] * Bp)[lb] + (pg ? pg[dc[j]] : 0.0);
+  }
+  for (int r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int j = 0; j < GW + 1; ++j) {
+      lbn[j] = (pl + rowX + (i64)dc[j] * Bp)[lb];
+      ubn[j] = (pu + rowX + (i64)dc[j] * Bp)[lb] + (pg ? pg[W + dc[j]] : 0.0);
+    }
+    const i64 e0 = 2 * ((i64)r * nx + c0);               // element 2 q of quad (r, c0)
+#pragma unroll
+    for (int j = 0; j < GW; ++j) {
+      if (c0 + j >= nx) continue;
+      const i64 e = e0 + 2 * j;
+      // T0 = [a, b, d]: a = (r, c), b = (r, c + 1), d = (r + 1, c)
+      {
+        const double lp[3] = {la[j], la[j + 1], lbn[j]}, uq[3] = {ua[j], ua[j + 1], ubn[j]};
+        double acc = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < 3; ++p_)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * m + e] * uq[q];
+        (dk + e * Bp)[lb] = -acc;
+      }
+      // T1 = [b, c, d]: b = (r, c + 1), c = (r + 1, c + 1), d = (r + 1, c)
+      {
+        const double lp[3] = {la[j + 1], lbn[j + 1], lbn[j]}, uq[3] = {ua[j + 1], ubn[j + 1], ubn[j]};
+        double acc = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < 3; ++p_)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * m + e + 1] * uq[q];
+        (dk + (e + 1) * Bp)[lb] = -acc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GW + 1; ++j) {
+      la[j] = lbn[j];
+      ua[j] = ubn[j];
+    }
+    pl += rowX;
+    pu += rowX;
+    if (pg) pg += W;
+  }
+}
+
+extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u,
+                                         const double* g, double* dk, int Bp, void* stream) {
+  if (!k0 || !lam || !u || !dk || nx < 2 || ny < 2) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
+  if (Bp < kWave) return DIFFHE_E_TOOBIG;              // small batches: diffhe_p1_grad_kappa
+  const int ncb = (nx + 4 * kGradCols - 1) / (4 * kGradCols);
+  const int gy = Bp / kWave;
+  int nrc = (6144 + ncb * gy - 1) / (ncb * gy);
+  if (nrc > ny / 8) nrc = ny / 8;
+  if (nrc < 1) nrc = 1;
+  const int TR = (ny + nrc - 1) / nrc;
+  nrc = (ny + TR - 1) / TR;
+  diffhe::account(32.0 * (double)(nx + 1) * (ny + 1) * Bp);   // lambda, u once per node; two dk per node
+  hipLaunchKernelGGL(lattice_grad_kappa_kernel, dim3(ncb * nrc, gy), dim3(256), 0, (hipStream_t)stream, nx, ny, k0, lam, u, g,
+                     dk, Bp, ncb, TR);
+  return diffhe::check_launch();
+}
+
 // fp32 diagonal + bf16 off-diagonals of a per-sample symmetric-diagonal matrix (bf16m above): off-diagonals rounded to
 // nearest-even bf16, the diagonal moved by the sum of the rounding differences of the row's 2 (nd - 1) couplings so that
 // the row sum is the fp64 matrix's (to fp32 rounding of the diagonal itself, 6e-8 relative).

@@ -68,6 +68,7 @@ SIGNATURES = {
     "diffhe_lattice_apply_shared": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pack_bf16": (_I, [_LV, _I, _P, _P, _P]),
+    "diffhe_lattice_grad_kappa": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "diffhe_p1_grad_kappa_shared": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

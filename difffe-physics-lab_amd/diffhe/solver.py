@@ -310,8 +310,16 @@ class _Engine:
         for lev, v in zip(p.levels, vals):
             one = (_hip.MgLevel * 1)()
             one[0].nx, one[0].ny, one[0].nd, one[0].vals = lev.nx, lev.ny, lev.nd, v.data_ptr()
-            d = torch.empty((lev.n, Bv), dtype=torch.float32, device=p.device)
-            o = torch.empty((lev.nd - 1, lev.n, Bv), dtype=torch.int16, device=p.device)
+            # The strip kernels read one row + one column BEFORE a diagonal's first entry (column -1 of row 0: the value
+            # is multiplied by a zero window entry, but it must be mapped, finite memory): both arrays get a zeroed
+            # guard of (W + 1) rows of samples in front.
+            pad = (lev.nx + 2) * Bv
+            dbuf = torch.empty(pad + lev.n * Bv, dtype=torch.float32, device=p.device)
+            obuf = torch.empty(pad + (lev.nd - 1) * lev.n * Bv, dtype=torch.int16, device=p.device)
+            dbuf[:pad].zero_()
+            obuf[:pad].zero_()
+            d = dbuf[pad:].view(lev.n, Bv)
+            o = obuf[pad:].view(lev.nd - 1, lev.n, Bv)
             _hip.check(L.diffhe_lattice_pack_bf16(one, Bv, _hip.ptr(d), _hip.ptr(o), _stream(p.device)),
                        "diffhe_lattice_pack_bf16")
             d32.append(d)
@@ -427,6 +435,13 @@ class _Engine:
 
     def grad_kappa(self, lam, x, Bp, want_elem):
         p, L = self.p, self.L
+        if want_elem and p.is_lattice and Bp >= 64:
+            # lattice mesh, per-element gradient of every sample: strip pass (each nodal value read once per wave)
+            lev = p.levels[0]
+            dk_e = torch.empty((p.m, Bp), dtype=torch.float64, device=p.device)
+            _hip.check(L.diffhe_lattice_grad_kappa(lev.nx, lev.ny, _hip.ptr(lev.k0), _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
+                                                   _hip.ptr(dk_e), Bp, _stream(p.device)), "diffhe_lattice_grad_kappa")
+            return dk_e, None
         nblk = L.diffhe_grad_kappa_blocks(p.m, Bp)
         dk_e = torch.empty((p.m, Bp), dtype=torch.float64, device=p.device) if want_elem else None
         part = torch.empty((nblk, Bp), dtype=torch.float64, device=p.device)

@@ -330,6 +330,12 @@ int diffhe_lattice_bilinear(const diffhe_mg_level* level, int Bv, const double* 
 int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, const double* x, const double* sub,
                                 int sub_B, const double* sub_scale, const unsigned char* mask, double* y, int Bp,
                                 void* stream);
+/* dk[e, b] = - sum_{p,q} lambda[node_p, b] k0[p*3+q, e] (u[node_q, b] + g[node_q]) for every element of a LATTICE mesh
+ * (FEMesh.rectangle connectivity) and every sample: the per-element gradient of diffhe_p1_grad_kappa as a strip pass
+ * (each nodal value loaded once per wave instead of once per incident element).  k0 (9, m) unit-kappa element
+ * matrices, lam / u (n, Bp), g (n) or NULL, dk (m, Bp).  DIFFHE_E_TOOBIG for Bp < 64 (use diffhe_p1_grad_kappa). */
+int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u, const double* g,
+                              double* dk, int Bp, void* stream);
 /* Compact coefficient copies of a per-sample matrix for the fp32-stored V-cycle (diffhe_mg_level.vals32 / offdiag16):
  * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) bf16 (round to nearest even); the diagonal absorbs the rounding
  * differences of its row's couplings, so the row sums -- what the smooth error modes see -- are those of `vals`. */
