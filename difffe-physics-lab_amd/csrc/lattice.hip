@@ -25,8 +25,10 @@ struct Level {
   int nx, ny, n, W, nd;
   const double* v;          // (nd, n, Bv)
   const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels
-  const unsigned short* o16;  // optional bf16 off-diagonals (nd - 1, n, Bv) of a per-sample matrix (Bv == Bp): with it v32 holds
-                            // ONLY the main diagonal (n, Bv), adjusted so that every row sum equals the fp64 matrix's
+  const _Float16* o16;      // optional fp16 off-diagonals (nd - 1, n, Bv), times 1 / oscale, of a per-sample matrix (Bv == Bp):
+                            // with it v32 holds ONLY the main diagonal (n, Bv), adjusted so that every row sum equals
+                            // the fp64 matrix's
+  double oscale;            // power of two >= the largest diagonal entry: stored off-diagonals lie in [-1, 1]
   const float* rd32;        // optional (n) fp32 reciprocal of the main diagonal of a batch-SHARED level matrix (Bv == 1):
                             // with v32 and mk32 it switches the fp32 V-cycle to the two-samples-per-lane strip kernels
   const float* mk32;        // (n) 0.0f on Dirichlet rows, 1.0f elsewhere (scalar-loadable form of bc)
@@ -38,23 +40,20 @@ struct Level {
 
 __device__ inline double shift_at(const Level& L, int i) { return L.shift ? L.shift[i] : 0.0; }
 
-// Matrix-value storage of the strip kernels: fp64; fp32 copies (fp32 V-cycle, per-sample matrices); or `bf16m`: fp32 main
-// diagonal + bf16 off-diagonals (8 instead of 12 B per node and sample for 3 diagonals).  The preconditioner only has to
-// be spectrally close to A: rounding an edge weight to bf16 (2^-9 relative) while the diagonal keeps every ROW SUM of the
-// fp64 matrix perturbs A by a graph Laplacian with edge weights 2^-9 |a_ij| -- spectrally equivalent within 0.4 %, the
-// null-space behaviour of the smooth modes untouched (a rounded diagonal would shift them by 2^-9 |a_ii| >> lambda_min).
-struct bf16m {};   // tag type
+// Matrix-value storage of the strip kernels: fp64; fp32 copies (fp32 V-cycle, per-sample matrices); or `h16m`: fp32 main
+// diagonal + fp16 off-diagonals (8 instead of 12 B per node and sample for 3 diagonals).  The preconditioner only has to
+// be spectrally close to A: rounding an edge weight to fp16 (2^-11 relative) while the diagonal keeps every ROW SUM of
+// the fp64 matrix perturbs A by a graph Laplacian with edge weights 2^-11 |a_ij| -- spectrally equivalent within 0.1 %,
+// the null-space behaviour of the smooth modes untouched (a rounded diagonal would shift them by 2^-11 |a_ii| >>
+// lambda_min).  Range: the off-diagonals are stored divided by a power of two >= the largest diagonal entry (|a_ij| <=
+// max a_ii for an SPD matrix), so kappa of any magnitude fits; bf16 (no scaling needed) was measured one PCG iteration
+// worse on the bench workload (10 + 10 against 9 + 9).
+struct h16m {};   // tag type
 template <typename TM> struct MatTypes { typedef TM diag; typedef TM off; };
-template <> struct MatTypes<bf16m> { typedef float diag; typedef unsigned short off; };
+template <> struct MatTypes<h16m> { typedef float diag; typedef _Float16 off; };
 __device__ __forceinline__ double ldc(const double* __restrict__ p, unsigned lv) { return p[lv]; }
 __device__ __forceinline__ double ldc(const float* __restrict__ p, unsigned lv) { return (double)p[lv]; }
-__device__ __forceinline__ double ldc(const unsigned short* __restrict__ p, unsigned lv) {
-  return (double)__uint_as_float((unsigned)p[lv] << 16);
-}
-__device__ __forceinline__ unsigned short to_bf16(double v) {   // round to nearest even
-  const unsigned u = __float_as_uint((float)v);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ __forceinline__ double ldc(const _Float16* __restrict__ p, unsigned lv) { return (double)(float)p[lv]; }
 
 // 1/d for the smoother: hardware v_rcp_f64 (~2^-23 relative) + one Newton step (~1e-14) -- 4 instructions
 // instead of the ~30 of an IEEE fp64 division.  D^-1 only has to be the same positive diagonal everywhere in
@@ -247,7 +246,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
   typedef typename MatTypes<TM>::diag TD;
   typedef typename MatTypes<TM>::off TO;
-  constexpr bool kSplit = sizeof(TO) == 2;   // bf16m: diagonal in L.v32, off-diagonals in L.o16
+  constexpr bool kSplit = sizeof(TO) == 2;   // h16m: diagonal in L.v32, off-diagonals in L.o16 (times 1 / L.oscale)
+  const double osc = kSplit ? L.oscale : 1.0;
   const TD* __restrict__ p0 = (sizeof(TD) == 4 ? (const TD*)L.v32 : (const TD*)L.v) + i0 * Bv;
   const TO* __restrict__ p1 = kSplit ? (const TO*)L.o16 + i0 * Bv : (const TO*)(const void*)(p0 + n * Bv);
   const TO* __restrict__ p2 = p1 + n * Bv;
@@ -319,9 +319,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   if (r0 > 0) load_window(r0 - 1, -rowX, px - rowX, p0 - rowV, xm, SHIFT ? psh - W : nullptr);
   load_window(r0, 0, px, p0, xc, psh);
 #pragma unroll
-  for (int k = 0; k < RW; ++k) n2p[k] = ldc(p2 - rowV + (i64)dq[k + 1] * Bv, lv);
+  for (int k = 0; k < RW; ++k) n2p[k] = kSplit ? osc * ldc(p2 - rowV + (i64)dq[k + 1] * Bv, lv) : ldc(p2 - rowV + (i64)dq[k + 1] * Bv, lv);
 #pragma unroll
-  for (int k = 0; k < RW + 1; ++k) d3p[k] = (ND == 4) ? ldc(p3 - rowV + (i64)dq[k + 1] * Bv, lv) : 0.0;
+  for (int k = 0; k < RW + 1; ++k)
+    d3p[k] = (ND == 4) ? (kSplit ? osc * ldc(p3 - rowV + (i64)dq[k + 1] * Bv, lv) : ldc(p3 - rowV + (i64)dq[k + 1] * Bv, lv)) : 0.0;
 
   constexpr int CWR = (FUSE == F_RESTRICT) ? (RW - 1) / 2 : 1;  // coarse columns of an F_RESTRICT strip
   double racc[CWR], rnext[CWR];
@@ -345,15 +346,15 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
       d0[k] = ldc(p0 + (i64)dq[k + 1] * Bv, lv);
-      n2c[k] = ldc(p2 + (i64)dq[k + 1] * Bv, lv);
+      n2c[k] = kSplit ? osc * ldc(p2 + (i64)dq[k + 1] * Bv, lv) : ldc(p2 + (i64)dq[k + 1] * Bv, lv);
     }
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) {
       // east coupling of column c0w-1+k; column -1 reads the element before the row (valid
       // memory, multiplied by a zero window value)
       const int dc = TAIL ? dq[k] : k - 1;
-      e1[k] = ldc(p1 + (i64)dc * Bv, lv);
-      d3c[k] = (ND == 4) ? ldc(p3 + (i64)dq[k + 1] * Bv, lv) : 0.0;
+      e1[k] = kSplit ? osc * ldc(p1 + (i64)dc * Bv, lv) : ldc(p1 + (i64)dc * Bv, lv);
+      d3c[k] = (ND == 4) ? (kSplit ? osc * ldc(p3 + (i64)dq[k + 1] * Bv, lv) : ldc(p3 + (i64)dq[k + 1] * Bv, lv)) : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -900,7 +901,7 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
   dim3 grid(g.ncb * g.nrc, Bp / kWave);
   // per-sample matrices inside the fp32 V-cycle read the fp32 copy of the coefficients
   const bool m32 = (sizeof(TV) == 4) && Bv != 1 && L.v32 != nullptr;
-  const bool m16 = m32 && L.o16 != nullptr;   // fp32 diagonal + bf16 off-diagonals
+  const bool m16 = m32 && L.o16 != nullptr;   // fp32 diagonal + fp16 off-diagonals
   {  // algorithmic bytes per (node, sample) of this launch (diffhe_traffic_account)
     const double tv = sizeof(TV), ta = sizeof(TA);
     double bpn;
@@ -922,9 +923,9 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
   if (Bv == 1 && L.shift) {
     if (L.nd == 3) STRIP_SHIFT(3); else STRIP_SHIFT(4);
   } else if (L.nd == 3) {
-    if (Bv == 1) STRIP(3, true, double); else if (m16) STRIP(3, false, bf16m); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
+    if (Bv == 1) STRIP(3, true, double); else if (m16) STRIP(3, false, h16m); else if (m32) STRIP(3, false, float); else STRIP(3, false, double);
   } else {
-    if (Bv == 1) STRIP(4, true, double); else if (m16) STRIP(4, false, bf16m); else if (m32) STRIP(4, false, float); else STRIP(4, false, double);
+    if (Bv == 1) STRIP(4, true, double); else if (m16) STRIP(4, false, h16m); else if (m32) STRIP(4, false, float); else STRIP(4, false, double);
   }
 #undef STRIP
 #undef STRIP_SHIFT
@@ -1873,7 +1874,8 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32; L.mk32 = s.mask32; L.o16 = (Bv == Bp && Bp > 1) ? s.offdiag16 : nullptr;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32; L.mk32 = s.mask32; L.o16 = (Bv == Bp && Bp > 1 && s.offdiag_scale > 0.0) ? (const _Float16*)s.offdiag16 : nullptr;
+    L.oscale = s.offdiag_scale;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
@@ -2258,7 +2260,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   Level L{};   // inv, shift: none
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
-  L.rd32 = nullptr; L.mk32 = nullptr; L.o16 = nullptr;
+  L.rd32 = nullptr; L.mk32 = nullptr; L.o16 = nullptr; L.oscale = 0.0;
   const StripGeom g = strip_geom(L, Bp);
   if (g.use && (!sub || sub_B == 1)) {
     Extra ex{};
@@ -2382,14 +2384,15 @@ extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const
   return diffhe::check_launch();
 }
 
-// fp32 diagonal + bf16 off-diagonals of a per-sample symmetric-diagonal matrix (bf16m above): off-diagonals rounded to
-// nearest-even bf16, the diagonal moved by the sum of the rounding differences of the row's 2 (nd - 1) couplings so that
-// the row sum is the fp64 matrix's (to fp32 rounding of the diagonal itself, 6e-8 relative).
-__global__ __launch_bounds__(256) void dia_pack_bf16_kernel(Level L, int Bv, float* __restrict__ d32,
-                                                             unsigned short* __restrict__ o16) {
+// fp32 diagonal + fp16 off-diagonals of a per-sample symmetric-diagonal matrix (h16m above): off-diagonals divided by
+// `oscale` and rounded to fp16, the diagonal moved by the sum of the rounding differences of the row's 2 (nd - 1)
+// couplings so that the row sum is the fp64 matrix's (to the fp32 rounding of the diagonal itself, 6e-8 relative).
+__global__ __launch_bounds__(256) void dia_pack_h16_kernel(Level L, int Bv, double oscale, float* __restrict__ d32,
+                                                            _Float16* __restrict__ o16) {
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
   const i64 n = L.n;
+  const double inv = 1.0 / oscale;   // power of two: exact
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     double d = L.v[(i64)i * Bv + nm.b];
 #pragma unroll
@@ -2397,12 +2400,12 @@ __global__ __launch_bounds__(256) void dia_pack_bf16_kernel(Level L, int Bv, flo
       if (k < L.nd) {
         const int off = dia_off(L, k);
         const double up = L.v[((i64)k * n + i) * Bv + nm.b];            // coupling (i, i + off): stored here
-        const unsigned short h = to_bf16(up);
+        const _Float16 h = (_Float16)(float)(up * inv);
         o16[((i64)(k - 1) * n + i) * Bv + nm.b] = h;
-        if (i + off < L.n) d += up - (double)__uint_as_float((unsigned)h << 16);
+        if (i + off < L.n) d += up - oscale * (double)(float)h;
         if (i - off >= 0) {                                             // coupling (i - off, i): stored at the other end
           const double lo = L.v[((i64)k * n + (i - off)) * Bv + nm.b];
-          d += lo - (double)__uint_as_float((unsigned)to_bf16(lo) << 16);
+          d += lo - oscale * (double)(float)(_Float16)(float)(lo * inv);
         }
       }
     }
@@ -2410,15 +2413,17 @@ __global__ __launch_bounds__(256) void dia_pack_bf16_kernel(Level L, int Bv, flo
   }
 }
 
-extern "C" int diffhe_lattice_pack_bf16(const diffhe_mg_level* level, int Bv, float* diag32, unsigned short* offdiag16,
-                                        void* stream) {
-  if (!level || !diag32 || !offdiag16 || !level->vals || (level->nd != 3 && level->nd != 4)) return DIFFHE_E_BADARG;
+extern "C" int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, double offdiag_scale, float* diag32,
+                                       void* offdiag16, void* stream) {
+  if (!level || !diag32 || !offdiag16 || !level->vals || (level->nd != 3 && level->nd != 4) || !(offdiag_scale > 0.0))
+    return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
   Level L{};
   L.nx = level->nx; L.ny = level->ny; L.W = level->nx + 1; L.n = (level->nx + 1) * (level->ny + 1); L.nd = level->nd;
   L.v = level->vals;
   diffhe::account((8.0 * L.nd + 4.0 + 2.0 * (L.nd - 1)) * (double)L.n * Bv);
-  hipLaunchKernelGGL(dia_pack_bf16_kernel, node_grid(L.n, Bv), dim3(256), 0, (hipStream_t)stream, L, Bv, diag32, offdiag16);
+  hipLaunchKernelGGL(dia_pack_h16_kernel, node_grid(L.n, Bv), dim3(256), 0, (hipStream_t)stream, L, Bv, offdiag_scale,
+                     diag32, (_Float16*)offdiag16);
   return diffhe::check_launch();
 }
 

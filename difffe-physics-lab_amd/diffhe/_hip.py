@@ -19,7 +19,7 @@ ABI_VERSION = 6     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding wa
 class MgLevel(C.Structure):
     """struct diffhe_mg_level (include/diffhe_hip.h)."""
     _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P), ("vals32", _P),
-                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P), ("mask32", _P), ("offdiag16", _P)]
+                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P), ("mask32", _P), ("offdiag16", _P), ("offdiag_scale", _D)]
 
 
 _LV = C.POINTER(MgLevel)
@@ -67,7 +67,7 @@ SIGNATURES = {
     "diffhe_lattice_bilinear": (_I, [_LV, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_lattice_apply_shared": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "diffhe_lattice_pack_bf16": (_I, [_LV, _I, _P, _P, _P]),
+    "diffhe_lattice_pack_h16": (_I, [_LV, _I, _D, _P, _P, _P]),
     "diffhe_lattice_grad_kappa": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),

@@ -303,9 +303,16 @@ class _Engine:
         return vals, Bv, scale, lift, scale
 
     def pack_cycle_coeffs(self, vals, Bv):
-        """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, bf16 off-diagonals) per level -- 8 instead of 12 B
-        of coefficients per node and sample (3 diagonals); every row sum of the fp64 matrix is kept."""
+        """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, fp16 off-diagonals, scale) per level -- 8 instead of
+        12 B of coefficients per node and sample (3 diagonals); every row sum of the fp64 matrix is kept.  The
+        off-diagonals are stored divided by a power of two >= the largest diagonal entry of the fine level (one
+        reduction pass), so kappa of any magnitude stays inside the fp16 range."""
+        import math
         p, L = self.p, self.L
+        dmax = float(vals[0][0].amax())
+        if not (dmax > 0.0) or not math.isfinite(dmax):
+            return None, None, 0.0
+        scale = 2.0 ** math.ceil(math.log2(dmax))
         d32, o16 = [], []
         for lev, v in zip(p.levels, vals):
             one = (_hip.MgLevel * 1)()
@@ -315,18 +322,19 @@ class _Engine:
             # guard of (W + 1) rows of samples in front.
             pad = (lev.nx + 2) * Bv
             dbuf = torch.empty(pad + lev.n * Bv, dtype=torch.float32, device=p.device)
-            obuf = torch.empty(pad + (lev.nd - 1) * lev.n * Bv, dtype=torch.int16, device=p.device)
+            obuf = torch.empty(pad + (lev.nd - 1) * lev.n * Bv, dtype=torch.float16, device=p.device)
             dbuf[:pad].zero_()
             obuf[:pad].zero_()
             d = dbuf[pad:].view(lev.n, Bv)
             o = obuf[pad:].view(lev.nd - 1, lev.n, Bv)
-            _hip.check(L.diffhe_lattice_pack_bf16(one, Bv, _hip.ptr(d), _hip.ptr(o), _stream(p.device)),
-                       "diffhe_lattice_pack_bf16")
+            _hip.check(L.diffhe_lattice_pack_h16(one, Bv, scale, _hip.ptr(d), _hip.ptr(o), _stream(p.device)),
+                       "diffhe_lattice_pack_h16")
             d32.append(d)
             o16.append(o)
-        return d32, o16
+        return d32, o16, scale
 
     def lattice_levels(self, vals, vals32=None, dense=None, shift=None, rdiag32=None, off16=None):
+        off16, oscale = off16 if off16 is not None else (None, 0.0)
         """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
         level, whose solve becomes one dense product (diffhe_mg_level.dense_inv).  shift = per-level (n,) diagonal
         shifts of a factored operator (diffhe_mg_level.shift)."""
@@ -341,6 +349,7 @@ class _Engine:
             arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
             arr[i].mask32 = lev.mask32().data_ptr() if arr[i].rdiag32 else None
             arr[i].offdiag16 = off16[i].data_ptr() if off16 is not None and off16[i] is not None else None
+            arr[i].offdiag_scale = oscale if arr[i].offdiag16 else 0.0
         return arr
 
     def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None,
@@ -630,9 +639,11 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # matrix gets an fp32 copy and the reciprocal of its main diagonal (a few MB), which switch the strip levels
         # to the two-samples-per-lane kernels (packed fp32 arithmetic; batches that are multiples of 128, no shift)
         vals32 = rdiag32 = off16 = None
-        if mg.get("fp32") and Bv != 1 and mg.get("bf16", 1) and Bp > 1:
-            vals32, off16 = eng.pack_cycle_coeffs(vals, Bv)      # fp32 diagonal + bf16 off-diagonals (row sums kept)
-        elif mg.get("fp32") and Bv != 1:
+        if mg.get("fp32") and Bv != 1 and mg.get("h16", 1) and Bp > 1:
+            d32_, o16_, osc_ = eng.pack_cycle_coeffs(vals, Bv)   # fp32 diagonal + fp16 off-diagonals (row sums kept)
+            if d32_ is not None:
+                vals32, off16 = d32_, (o16_, osc_)
+        if mg.get("fp32") and Bv != 1 and vals32 is None:
             vals32 = [v.float() for v in vals]
         elif mg.get("fp32") and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
             vals32, rdiag32 = plan.shared_fp32(vals, cacheable=factored and kappa_free_unit)

@@ -244,10 +244,13 @@ typedef struct diffhe_mg_level {
                                   arithmetic, no division); needs mask32, Bp % 128 == 0 and no shift; NULL = the
                                   fp64-in-registers kernels */
   const float* mask32;         /* with rdiag32: (n) 0.0f on Dirichlet rows, 1.0f elsewhere (is_bc as scalar-loadable floats) */
-  const unsigned short* offdiag16; /* optional, Bv == Bp only (ABI v6): bf16 off-diagonals (nd - 1, n, Bv); vals32 is then
-                                  the (n, Bv) fp32 main diagonal adjusted to keep every row sum of `vals`
-                                  (diffhe_lattice_pack_bf16 produces both): 4 + 2 (nd - 1) instead of 4 nd bytes of
-                                  coefficients per node and sample in the fp32-stored V-cycle */
+  const void* offdiag16;       /* optional, Bv == Bp only (ABI v6): fp16 off-diagonals (nd - 1, n, Bv) divided by
+                                  offdiag_scale; vals32 is then the (n, Bv) fp32 main diagonal adjusted to keep every row
+                                  sum of `vals` (diffhe_lattice_pack_h16 produces both): 4 + 2 (nd - 1) instead of 4 nd
+                                  bytes of coefficients per node and sample in the fp32-stored V-cycle.  Both arrays must
+                                  be preceded by (nx + 2) * Bv readable, zeroed elements (the strip kernels read one row
+                                  and one column before a diagonal's first entry) */
+  double offdiag_scale;        /* power of two >= the largest diagonal entry of `vals` (0 = offdiag16 unused) */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
@@ -337,9 +340,11 @@ int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, cons
 int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u, const double* g,
                               double* dk, int Bp, void* stream);
 /* Compact coefficient copies of a per-sample matrix for the fp32-stored V-cycle (diffhe_mg_level.vals32 / offdiag16):
- * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) bf16 (round to nearest even); the diagonal absorbs the rounding
- * differences of its row's couplings, so the row sums -- what the smooth error modes see -- are those of `vals`. */
-int diffhe_lattice_pack_bf16(const diffhe_mg_level* level, int Bv, float* diag32, unsigned short* offdiag16, void* stream);
+ * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) fp16 of vals / offdiag_scale (a power of two >= max diagonal); the
+ * diagonal absorbs the rounding differences of its row's couplings, so the row sums -- what the smooth error modes see
+ * -- are those of `vals`. */
+int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, double offdiag_scale, float* diag32, void* offdiag16,
+                            void* stream);
 /* kappa of the coarse triangulation, arrays (m, Bv); sx, sy in {1, 2} = coarsening factor per direction.
  * Full coarsening: mean of the 4 children of each coarse triangle; semi: mean over the 2 covered fine cells. */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,
