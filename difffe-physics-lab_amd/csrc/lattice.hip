@@ -1295,6 +1295,7 @@ struct PcgScalars {
   double* rr;             // last r.r per sample (guard of the energy stop)
   double* est;            // out: last estimate sqrt(r.z / energy) per sample
   double tol_e2;          // 0: residual criterion only
+  int e_max_it;           // the energy rule is trusted within this many iterations (10 at tol_energy 1e-11, one more per decade)
   int have_energy;        // energy[] was set from the full-multigrid start (S_ENERGY)
   int* rule;              // out: which rule ended each sample: 0 none (iteration cap), 1 residual, 2 energy-norm estimate
 };
@@ -1379,11 +1380,12 @@ __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const doubl
         // (a V-cycle that lost definiteness -- obtuse meshes, fp32 overflow -- can return anything), a positive
         // energy bound, and a residual already within 1e4 x the target (|r|/|b| is 6e-9 .. 2e-10 at the iterations
         // where the bench workload stops); otherwise the residual criterion decides alone.
-        // ... and only within the first 10 iterations: r.z equals e^T A e up to lambda_min(M^-1 A), and a CG that needs
+        // ... and only within the first 10 iterations (at tol_energy = 1e-11; one more per decade asked beyond that --
+        // a healthy cycle gains a decade per iteration): r.z equals e^T A e up to lambda_min(M^-1 A), and a CG that needs
         // more than that to get here is telling that this constant is small (skewed lattices with pinned interior
         // nodes: 12 and 35 iterations, error 8e-11 at an estimate of 1e-11).
         if (S.tol_e2 > 0.0 && a > 0.0 && S.energy[b] > 0.0 && e2 <= S.tol_e2 * S.energy[b] &&
-            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b] && S.iters[b] <= 10) {
+            S.rr[b] <= 1e8 * S.tol_e2 * S.bb[b] && S.iters[b] <= S.e_max_it) {
           S.active[b] = 0;
           S.rule[b] = 2;
         }
@@ -1968,6 +1970,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   // (pcg_finish_kernel): the CG iterate's own estimate may be 1 / 0.3 of it (0.3: a cautious bound of the V(2,2)
   // cycle's convergence factor; measured reductions of the nodal error by that step: 5-8x)
   S.tol_e2 = tol_energy > 0.0 ? (tol_energy / 0.3) * (tol_energy / 0.3) : 0.0;
+  S.e_max_it = 10 + ((tol_energy > 0.0 && tol_energy < 1e-11) ? (int)ceil(log10(1e-11 / tol_energy) - 1e-9) : 0);
   S.have_energy = 0;
   if (use_floor && use_fmg) {
     rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));

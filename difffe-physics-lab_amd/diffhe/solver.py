@@ -645,7 +645,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
                 vals32, off16 = d32_, (o16_, osc_)
         if mg.get("fp32") and Bv != 1 and vals32 is None:
             vals32 = [v.float() for v in vals]
-        elif mg.get("fp32") and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
+        elif mg.get("fp32") and Bv == 1 and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
             vals32, rdiag32 = plan.shared_fp32(vals, cacheable=factored and kappa_free_unit)
         dense = None
         if didx is not None:
