@@ -1526,23 +1526,16 @@ int op_jacobi_first2(const Hier& H, int l, const TV* rhs, TV* xa, TV* xb, double
   return lgrid(L.n, H.Bp).x;
 }
 
-inline int resid_cols() {   // development knob: strip width of the fp64 residual passes (8 or 4 columns per wave)
-  static const int rw = getenv("DIFFHE_RES_RW") ? atoi(getenv("DIFFHE_RES_RW")) : 8;
-  return rw == 4 ? 4 : 8;
-}
-
 template <typename TV>
 int op_residual(const Hier& H, int l, const TV* rhs, const TV* x, TV* res, double* part, hipStream_t st,
                 int dot_bx = 0, double* part2 = nullptr) {
   const Level& L = H.lev[l];
-  const bool narrow = sizeof(TV) == 8 && resid_cols() == 4;
-  const StripGeom g = strip_geom(L, H.Bp, narrow ? 4 : kStripCols);
+  const StripGeom g = strip_geom(L, H.Bp);
   if (g.use) {
     Extra ex{};
     ex.dot_bx = dot_bx;
     ex.part2 = part2;
-    if (narrow) launch_strip<TV, M_RESID, false, F_NONE, TV, 4>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st, ex);
-    else launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st, ex);
+    launch_strip<TV, M_RESID, false>(L, H.Bv, H.scale, x, rhs, res, 0.0, 0.0, part, H.Bp, g, st, ex);
     return g.ncb * g.nrc;
   }
   LAUNCH((res ? 3 : 2) * sizeof(TV) + MATB(L), dia_residual_kernel<TV>, L.n, L, H.Bv, H.scale, rhs, x, res, part, H.Bp,
@@ -2101,20 +2094,15 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   };
   // r = b - A x (+ its fp32 copy, + the partials b.x and x.(A x) of the energy bound when asked for)
   auto residual_pass = [&](bool energy) {
-    const bool narrow = resid_cols() == 4;
-    const StripGeom gr = strip_geom(L0, Bp, narrow ? 4 : kStripCols);
+    const StripGeom gr = strip_geom(L0, Bp);
     if (gr.use && f32) {  // r and its fp32 copy in one pass
       Extra ex{};
       ex.r32 = r32;
       ex.rscale = S.rs;
       ex.dot_bx = energy ? 1 : 0;   // partial sums of this pass: b.x0 and x0.(A x0) (S_ENERGY / S_ENERGY2)
       ex.part2 = energy ? partB : nullptr;
-      if (narrow)
-        launch_strip<double, M_RESID, false, F_NONE, double, 4>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0,
-                                                                energy ? partA : (double*)nullptr, Bp, gr, st, ex);
-      else
-        launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, energy ? partA : (double*)nullptr,
-                                             Bp, gr, st, ex);
+      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, energy ? partA : (double*)nullptr,
+                                           Bp, gr, st, ex);
       nba = gr.ncb * gr.nrc;
     } else {
       nba = op_residual<double>(H, 0, b, (const double*)x, r, energy ? partA : (double*)nullptr, st, energy ? 1 : 0,
