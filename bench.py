@@ -671,9 +671,9 @@ def pmc_traffic(symbols, pass_bytes):
 # exact instantiations (rocprofv3 kernel names, `(anonymous namespace)::` stripped) of the six main kernels of the
 # headline configuration: fp32-stored V-cycle, factored (batch-shared) 3-diagonal operator
 KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, false, 4, 7>", "pcg_update_kernel",
-                       "dia_strip_kernel<float, float, double, 2, 0, 3, true, true, 4, 1>",
-                       "dia_strip_kernel<float, float, double, 1, 3, 3, true, false, 5, 1>",
-                       "dia_strip_kernel<float, float, double, 2, 1, 3, true, false, 4, 1>",
+                       "dia_strip2_kernel<2, 0, 3, true, 4, false, false>",
+                       "dia_strip2_kernel<1, 3, 3, false, 5, false, false>",
+                       "dia_strip2_kernel<2, 1, 3, false, 4, false, false>",
                        "dia_strip_kernel<float, float, double, 2, 0, 3, true, false, 4, 1>"]
 
 

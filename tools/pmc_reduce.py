@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
+KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
         "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel")
 
 

@@ -18,6 +18,9 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 0, 4", "fused CG step, z/p fp64", 4.0),
     ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step with the x update (isolated launches of bench.py only)", 4.5),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
+    ("dia_strip2_kernel<2, 0, 3, true", "first two Jacobi sweeps from 0 (fp32, two samples per lane)", 1.0),
+    ("dia_strip2_kernel<1, 3", "residual + restriction, residual never stored (fp32, two samples per lane)", 1.125),
+    ("dia_strip2_kernel<2, 1", "prolong + correct + Jacobi sweep (fp32, two samples per lane)", 1.625),
     ("dia_strip_kernel<float, float, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp32)", 1.0),
     ("dia_strip_kernel<float, float, double, 1, 3", "residual + restriction, residual never stored (fp32)", 1.125),
     ("dia_strip_kernel<float, float, double, 1, 0", "residual (fp32)", 1.5),
@@ -38,6 +41,8 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 0, 0, 4", "F = M f - lift (strip kernel)", 2.0),
     ("dia_strip_kernel<double, double, double, 0, 0, 3", "dL/dkappa bilinear form lambda^T K_1 u", 2.0),
     ("pcg_setx_kernel", "x = x0 (fp32 -> fp64)", 1.5),
+    ("lattice_grad_kappa_kernel", "per-element gradient, lattice strip pass", 4.0),
+    ("grad_kappa_shared_kernel", "gradient of a shared kappa field (summed over the batch)", 2.0),
 ]
 
 
