@@ -544,10 +544,13 @@ __global__ __launch_bounds__(256) void to_sample_major_kernel(const double* __re
 // ---------------------------------------------------------------------------------------
 // Aggregation multigrid for the general path (diffhe/amg.py builds the batch-shared hierarchy)
 // ---------------------------------------------------------------------------------------
-// coarse values = P^T A P for piecewise-constant P: plain sums of fine entries (per sample)
+// coarse values = P^T A P (per sample) from gather lists: plain sums of fine entries for piecewise-constant P
+// (weights == NULL), weighted sums w_c = P_iI P_jJ for a smoothed P.  The lists and weights are batch-shared
+// (wave-uniform loads), the fine values arrive as one contiguous row of samples per contribution.
 __global__ __launch_bounds__(256) void ell_galerkin_kernel(const double* __restrict__ vals_f,
                                                             const int* __restrict__ ent_ptr,
                                                             const int* __restrict__ contrib,
+                                                            const double* __restrict__ weights,
                                                             double* __restrict__ vals_c, int nc, int Wc, int Bv) {
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
@@ -555,7 +558,10 @@ __global__ __launch_bounds__(256) void ell_galerkin_kernel(const double* __restr
     for (int k = 0; k < Wc; ++k) {
       const i64 ent = (i64)k * nc + I;
       double v = 0.0;
-      for (int c = ent_ptr[ent]; c < ent_ptr[ent + 1]; ++c) v += vals_f[(i64)contrib[c] * Bv + nm.b];
+      if (weights)
+        for (int c = ent_ptr[ent]; c < ent_ptr[ent + 1]; ++c) v = fma(weights[c], vals_f[(i64)contrib[c] * Bv + nm.b], v);
+      else
+        for (int c = ent_ptr[ent]; c < ent_ptr[ent + 1]; ++c) v += vals_f[(i64)contrib[c] * Bv + nm.b];
       vals_c[ent * Bv + nm.b] = v;
     }
 }
@@ -616,17 +622,43 @@ __global__ __launch_bounds__(256) void ell_residual_out_kernel(const TM* __restr
   }
 }
 
-// rc[I] = sum of r over the members of aggregate I (fixed order)
+// rc = P^T r: rc[I] = sum over the members c of coarse node I (fixed order) of w_c r[member_c]; w == NULL: 1
+// (piecewise-constant aggregation: the plain sum over the aggregate)
 template <typename TV>
 __global__ __launch_bounds__(256) void agg_restrict_kernel(const TV* __restrict__ r, const int* __restrict__ agg_ptr,
-                                                            const int* __restrict__ members, TV* __restrict__ rc,
+                                                            const int* __restrict__ members,
+                                                            const double* __restrict__ w, TV* __restrict__ rc,
                                                             int nc, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
   for (int I = nm.node0; I < nc; I += nm.stride) {
     double s = 0.0;
-    for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s += (double)r[(i64)members[c] * Bp + nm.b];
+    if (w)
+      for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s = fma(w[c], (double)r[(i64)members[c] * Bp + nm.b], s);
+    else
+      for (int c = agg_ptr[I]; c < agg_ptr[I + 1]; ++c) s += (double)r[(i64)members[c] * Bp + nm.b];
     rc[(i64)I * Bp + nm.b] = (TV)s;
+  }
+}
+
+// x += scale * P e for a smoothed prolongation stored as ELL rows: p_cols / p_vals (pw, n), -1 = no entry
+template <typename TV>
+__global__ __launch_bounds__(256) void sa_prolong_add_kernel(const TV* __restrict__ e, const int* __restrict__ p_cols,
+                                                              const double* __restrict__ p_vals, int pw,
+                                                              TV* __restrict__ x, double scale, int n, int Bp) {
+  const NodeMap nm = node_map(Bp);
+  if (nm.b >= Bp) return;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    double s = 0.0;
+    bool any = false;
+    for (int k = 0; k < pw; ++k) {
+      const int I = p_cols[(i64)k * n + i];
+      if (I >= 0) {
+        s = fma(p_vals[(i64)k * n + i], (double)e[(i64)I * Bp + nm.b], s);
+        any = true;
+      }
+    }
+    if (any) x[(i64)i * Bp + nm.b] = (TV)((double)x[(i64)i * Bp + nm.b] + scale * s);
   }
 }
 
@@ -773,9 +805,13 @@ TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream
     else
       ALAUNCH((ell_residual_out_kernel<TV, double>), L.n, L.vals, L.cols, rhs, (const TV*)a, (TV*)H.res[l], L.n, L.W,
               H.Bp, H.Bv);
-    ALAUNCH(agg_restrict_kernel<TV>, C.n, (const TV*)H.res[l], L.agg_ptr, L.agg_members, (TV*)H.rhs[l + 1], C.n, H.Bp);
+    ALAUNCH(agg_restrict_kernel<TV>, C.n, (const TV*)H.res[l], L.agg_ptr, L.agg_members, L.agg_weights,
+            (TV*)H.rhs[l + 1], C.n, H.Bp);
     const TV* ec = amg_cycle<TV>(H, l + 1, (const TV*)H.rhs[l + 1], nullptr, st);
-    ALAUNCH(agg_prolong_add_kernel<TV>, L.n, ec, L.agg, a, H.scale, L.n, H.Bp);
+    if (L.p_cols)   // smoothed aggregation: P as ELL rows
+      ALAUNCH(sa_prolong_add_kernel<TV>, L.n, ec, L.p_cols, L.p_vals, L.p_width, a, H.scale, L.n, H.Bp);
+    else
+      ALAUNCH(agg_prolong_add_kernel<TV>, L.n, ec, L.agg, a, H.scale, L.n, H.Bp);
   }
   for (int s = 0; s < 2; ++s) {
     const double w = (s & 1) ? H.w0 : H.w1;  // reverse order: symmetric cycle
@@ -807,6 +843,7 @@ int amg_fill(AmgHier& H, const diffhe_amg_level* levels, int n_levels, int Bv, i
     const diffhe_amg_level& s = levels[l];
     if (s.n < 1 || s.W < 1 || !s.vals || !s.cols) return DIFFHE_E_BADARG;
     if (l < n_levels - 1 && (!s.agg || !s.agg_ptr || !s.agg_members)) return DIFFHE_E_BADARG;
+    if (s.p_cols && (!s.p_vals || !s.agg_weights || s.p_width < 1)) return DIFFHE_E_BADARG;
     H.lev[l] = s;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp;
@@ -974,12 +1011,13 @@ extern "C" int diffhe_ell_apply(const double* vals, const int* cols, const doubl
   return diffhe::check_launch();
 }
 
-extern "C" int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, double* vals_coarse,
-                                   int n_coarse, int W_coarse, int Bv, void* stream) {
+extern "C" int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, const double* weights,
+                                   double* vals_coarse, int n_coarse, int W_coarse, int Bv, void* stream) {
   if (!vals_fine || !ent_ptr || !contrib || !vals_coarse || n_coarse < 1 || W_coarse < 1) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  diffhe::account(8.0 * Bv * (double)n_coarse * W_coarse);   // the coarse values written; fine values re-read from cache
   hipLaunchKernelGGL(ell_galerkin_kernel, diffhe::node_grid(n_coarse, Bv), dim3(256), 0, (hipStream_t)stream, vals_fine,
-                     ent_ptr, contrib, vals_coarse, n_coarse, W_coarse, Bv);
+                     ent_ptr, contrib, weights, vals_coarse, n_coarse, W_coarse, Bv);
   return diffhe::check_launch();
 }
 

@@ -28,7 +28,7 @@ _LV = C.POINTER(MgLevel)
 class AmgLevel(C.Structure):
     """struct diffhe_amg_level (include/diffhe_hip.h)."""
     _fields_ = [("n", _I), ("W", _I), ("vals", _P), ("cols", _P), ("agg", _P), ("agg_ptr", _P), ("agg_members", _P),
-                ("vals32", _P)]
+                ("vals32", _P), ("agg_weights", _P), ("p_cols", _P), ("p_vals", _P), ("p_width", _I), ("reserved", _I)]
 
 
 _AV = C.POINTER(AmgLevel)
@@ -51,7 +51,7 @@ SIGNATURES = {
     "diffhe_ell_spmv_shared": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "diffhe_cg_workspace_doubles": (_L, [_I, _I]),
     "diffhe_ell_cg_solve": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
-    "diffhe_ell_galerkin": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "diffhe_ell_galerkin": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "diffhe_ell_amg_workspace_doubles": (_L, [_AV, _I, _I]),
     "diffhe_ell_amg_pcg_solve": (_I, [_AV, _I, _I, _P, _P, _I, _D, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P]),
     "diffhe_ell_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

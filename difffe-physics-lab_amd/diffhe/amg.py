@@ -149,3 +149,133 @@ def build_hierarchy(cols: np.ndarray, is_bc: np.ndarray, min_coarse: int = 64, m
         cur_cols = pat["cols"]
         active = np.ones(nc, dtype=bool)
     return levels
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Smoothed aggregation (round 3): same aggregates, prolongation smoothed by one damped-Jacobi step of the UNIT-kappa
+# operator, P = (I - omega D_1^-1 A_1) P_0.  P is batch-shared (built once per mesh from A_1); the coarse operators stay
+# per sample, A_c^b = P^T A_b P, as WEIGHTED sums of fine entries (gather lists with weights P_iI P_jJ).  Halves the
+# iteration count of the piecewise-constant hierarchy (256^2, CPU prototype: 68 -> 34) for ~1.6x denser coarse levels.
+# ---------------------------------------------------------------------------------------------------------------------
+def _ell_to_csr(cols: np.ndarray, vals: np.ndarray):
+    """(csr matrix, ELL index k*n+i of every stored nonzero in csr order) from an ELL pattern (slot 0 = diagonal,
+    padding slots point at the row itself)."""
+    import scipy.sparse as sp
+    W, n = cols.shape
+    k_idx, i_idx = np.meshgrid(np.arange(W, dtype=np.int64), np.arange(n, dtype=np.int64), indexing="ij")
+    real = (k_idx == 0) | (cols != i_idx)
+    r, c, e = i_idx[real], cols[real].astype(np.int64), (k_idx * n + i_idx)[real]
+    order = np.lexsort((c, r))
+    A = sp.csr_matrix((vals[real][order], (r[order], c[order])), shape=(n, n))
+    A.sum_duplicates()
+    assert A.nnz == len(order), "duplicate ELL entries"
+    return A, e[order]
+
+
+def _csr_to_ell(A):
+    """ELL pattern (W, n) with slot 0 = diagonal for a square CSR matrix with a full diagonal; also the slot index k*n+i of
+    every CSR nonzero (in CSR order)."""
+    n = A.shape[0]
+    A = A.tocsr()
+    A.sort_indices()
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.indptr))
+    colsA = A.indices.astype(np.int64)
+    isd = colsA == rows
+    # rank within the row with the diagonal first
+    pos = np.arange(A.nnz) - A.indptr[rows]
+    dpos = np.zeros(n, dtype=np.int64)
+    dpos[rows[isd]] = pos[isd]
+    slot = np.where(isd, 0, np.where(pos < dpos[rows], pos + 1, pos))
+    W = int(slot.max()) + 1
+    ell = np.tile(np.arange(n, dtype=np.int32), W).reshape(W, n)
+    ell[slot, rows] = colsA.astype(np.int32)
+    return ell, slot * n + rows
+
+
+def smoothed_level(A1, ell_index_f, cols_f, active, seed, omega=2.0 / 3.0, drop=0.0):
+    """One coarsening step.  A1: unit-kappa CSR matrix of the fine level; ell_index_f: ELL entry index (k*n_f + i) of each
+    of its nonzeros (CSR order); cols_f: its ELL pattern (for the aggregation).  Returns the level dict (device arrays as
+    numpy) and the coarse unit matrix with ITS ell index."""
+    import scipy.sparse as sp
+    nf = A1.shape[0]
+    agg = aggregate(cols_f, active, seed=seed)
+    nc = int(agg.max()) + 1
+    rows = np.nonzero(agg >= 0)[0]
+    P0 = sp.csr_matrix((np.ones(len(rows)), (rows, agg[rows])), shape=(nf, nc))
+    d = A1.diagonal()
+    S = sp.identity(nf, format="csr") - sp.diags(omega / d) @ A1
+    P = (sp.diags((agg >= 0).astype(np.float64)) @ S @ P0).tocsr()       # inactive (Dirichlet) rows interpolate nothing
+    if drop > 0.0:
+        P.data[np.abs(P.data) < drop] = 0.0
+    P.eliminate_zeros()
+    P.sort_indices()
+    Ac = (P.T @ A1 @ P).tocsr()
+    Ac.sort_indices()
+    cols_c, ell_index_c = _csr_to_ell(Ac)
+    Wc = cols_c.shape[0]
+    # --- weighted Galerkin gather lists: coarse entry (I, J) = sum over fine nonzeros (i, j) of P_iI a_ij P_jJ ---
+    fi = np.repeat(np.arange(nf, dtype=np.int64), np.diff(A1.indptr))
+    fj = A1.indices.astype(np.int64)
+    pn = np.diff(P.indptr).astype(np.int64)
+    keep = (pn[fi] > 0) & (pn[fj] > 0)
+    fi, fj, fe = fi[keep], fj[keep], ell_index_f[keep]
+    ca = pn[fi]                                                    # expand over the nonzeros of P's row i ...
+    t1 = np.repeat(np.arange(len(fi)), ca)
+    a_loc = np.arange(len(t1)) - np.repeat(np.cumsum(ca) - ca, ca)
+    pa = P.indptr[fi[t1]] + a_loc
+    cb = pn[fj[t1]]                                                # ... then over those of row j
+    t2 = np.repeat(np.arange(len(t1)), cb)
+    b_loc = np.arange(len(t2)) - np.repeat(np.cumsum(cb) - cb, cb)
+    pb = P.indptr[fj[t1[t2]]] + b_loc
+    I, J = P.indices[pa[t2]].astype(np.int64), P.indices[pb].astype(np.int64)
+    w = P.data[pa[t2]] * P.data[pb]
+    fine_entry = fe[t1[t2]]
+    # coarse ELL entry of (I, J): binary search in the sorted CSR keys of Ac
+    crow = np.repeat(np.arange(nc, dtype=np.int64), np.diff(Ac.indptr))
+    ckey = crow * nc + Ac.indices.astype(np.int64)
+    loc = np.searchsorted(ckey, I * nc + J)
+    assert np.array_equal(ckey[loc], I * nc + J)
+    centry = ell_index_c[loc]
+    order = np.argsort(centry, kind="stable")
+    ent_ptr = np.zeros(Wc * nc + 1, dtype=np.int64)
+    np.cumsum(np.bincount(centry, minlength=Wc * nc), out=ent_ptr[1:])
+    if ent_ptr[-1] >= 2 ** 31:
+        raise ValueError("mesh too large for int32 gather lists")
+    # --- transfer operators for the device: P as ELL rows (prolongation), P^T as CSR (restriction) ---
+    pw = int(pn.max()) if len(pn) else 1
+    p_cols = np.full((pw, nf), -1, dtype=np.int32)
+    p_vals = np.zeros((pw, nf), dtype=np.float64)
+    prow = np.repeat(np.arange(nf, dtype=np.int64), pn)
+    ploc = np.arange(P.nnz) - P.indptr[prow]
+    p_cols[ploc, prow] = P.indices
+    p_vals[ploc, prow] = P.data
+    PT = P.T.tocsr()
+    PT.sort_indices()
+    level = dict(n=nc, W=Wc, cols=cols_c, ent_ptr=ent_ptr.astype(np.int32), contrib=fine_entry[order].astype(np.int32),
+                 weights=w[order], agg=agg.astype(np.int32), agg_ptr=PT.indptr.astype(np.int32),
+                 agg_members=PT.indices.astype(np.int32), agg_weights=PT.data.astype(np.float64),
+                 p_cols=p_cols, p_vals=p_vals)
+    return level, Ac, ell_index_c
+
+
+def build_hierarchy_sa(cols: np.ndarray, unit_vals: np.ndarray, is_bc: np.ndarray, min_coarse: int = 64,
+                       max_levels: int = 12) -> List[Dict]:
+    """Smoothed-aggregation levels below the fine one.  cols (W, n), unit_vals (W, n): ELL pattern and UNIT-kappa values
+    of the Dirichlet-eliminated fine matrix (identity rows on Dirichlet nodes).  Each dict: the coarse pattern and
+    weighted Galerkin lists (n, W, cols, ent_ptr, contrib, weights) and the transfers from the level above (p_cols,
+    p_vals: P as ELL rows; agg_ptr, agg_members, agg_weights: P^T as CSR; agg: the underlying aggregates)."""
+    levels: List[Dict] = []
+    A1, ell_idx = _ell_to_csr(cols, unit_vals)
+    active = ~is_bc.astype(bool)
+    cur_cols = cols
+    while len(levels) < max_levels - 1:
+        n_active = int(active.sum())
+        if n_active <= min_coarse:
+            break
+        lev, Ac, ell_c = smoothed_level(A1, ell_idx, cur_cols, active, seed=len(levels))
+        if lev["n"] >= 0.7 * n_active:
+            break
+        levels.append(lev)
+        A1, ell_idx, cur_cols = Ac, ell_c, lev["cols"]
+        active = np.ones(lev["n"], dtype=bool)
+    return levels

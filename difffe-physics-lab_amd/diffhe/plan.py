@@ -607,22 +607,55 @@ class SolvePlan:
                    "diffhe_ell_assemble_rows(M)")
         self._ell_ready = True
 
-    def ensure_amg(self):
-        """Aggregation hierarchy of the general path (diffhe/amg.py), uploaded once per mesh."""
+    def ensure_amg(self, smoothed: bool = False):
+        """Aggregation hierarchy of the general path (diffhe/amg.py), uploaded once per mesh.  smoothed: the
+        smoothed-aggregation hierarchy (batch-shared P from the unit-kappa operator, weighted Galerkin lists) instead
+        of the piecewise-constant one.  Returns the list of device-side level dicts."""
         with self._build_lock:
-            self._ensure_amg()
+            return self._ensure_amg(smoothed)
 
-    def _ensure_amg(self):
-        if getattr(self, "amg_levels", None) is not None:
-            return
-        from .amg import build_hierarchy
+    def _ensure_amg(self, smoothed: bool = False):
+        attr = "amg_levels_sa" if smoothed else "amg_levels"
+        if getattr(self, attr, None) is not None:
+            return getattr(self, attr)
+        from .amg import build_hierarchy, build_hierarchy_sa
         self._ensure_ell()
         device = self.device
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
-        host = build_hierarchy(self.cols.cpu().numpy(), self.is_bc.cpu().numpy())
-        self.amg_levels = [dict(n=lv["n"], W=lv["W"], cols=dev(lv["cols"]), ent_ptr=dev(lv["ent_ptr"]),
-                                contrib=dev(lv["contrib"]), agg=dev(lv["agg"]), agg_ptr=dev(lv["agg_ptr"]),
-                                agg_members=dev(lv["agg_members"])) for lv in host]
+        if smoothed:
+            host = build_hierarchy_sa(self.cols.cpu().numpy(), self._unit_ell_values(), self.is_bc.cpu().numpy())
+        else:
+            host = build_hierarchy(self.cols.cpu().numpy(), self.is_bc.cpu().numpy())
+        levels = []
+        for lv in host:
+            d = dict(n=lv["n"], W=lv["W"], cols=dev(lv["cols"]), ent_ptr=dev(lv["ent_ptr"]), contrib=dev(lv["contrib"]),
+                     agg=dev(lv["agg"]), agg_ptr=dev(lv["agg_ptr"]), agg_members=dev(lv["agg_members"]))
+            if smoothed:
+                d.update(weights=dev(lv["weights"]), agg_weights=dev(lv["agg_weights"]), p_cols=dev(lv["p_cols"]),
+                         p_vals=dev(lv["p_vals"]))
+            levels.append(d)
+        setattr(self, attr, levels)
+        return levels
+
+    def _unit_ell_values(self) -> np.ndarray:
+        """(W, n) host copy of the Dirichlet-eliminated UNIT-kappa matrix in the ELL pattern (identity rows on Dirichlet
+        nodes): what the smoothed prolongation is built from.  Assembled by the device kernels the solve itself uses."""
+        L = _hip.lib()
+        vals = torch.empty((self.W, self.n, 1), dtype=torch.float64, device=self.device)
+        lift = torch.empty((self.n, 1), dtype=torch.float64, device=self.device)
+        one = torch.ones(1, dtype=torch.float64, device=self.device)
+        st = _stream(self.device)
+        if self.is_p2:
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(self.k0), _hip.ptr(one), 0, 0, _hip.ptr(self.ent_ptr),
+                                                  _hip.ptr(self.contrib), _hip.ptr(self.cols), None, _hip.ptr(self.is_bc),
+                                                  _hip.ptr(self.g), _hip.ptr(vals), _hip.ptr(lift), self.n, self.m, self.W, 1,
+                                                  st), "diffhe_ell_assemble_rows(unit)")
+        else:
+            _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(self.tnum), _hip.ptr(self.den), _hip.ptr(one), 0, 0,
+                                                      _hip.ptr(self.ent_ptr), _hip.ptr(self.contrib), _hip.ptr(self.cols), None,
+                                                      _hip.ptr(self.is_bc), _hip.ptr(self.g), _hip.ptr(vals), _hip.ptr(lift),
+                                                      self.n, self.m, self.W, 1, st), "diffhe_ell_assemble_rows_ref(unit)")
+        return vals.reshape(self.W, self.n).cpu().numpy()
 
 
 def _stream(device):

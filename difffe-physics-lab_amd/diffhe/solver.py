@@ -385,17 +385,19 @@ class _Engine:
         return x, int(st[0]), int(st[1]), relres
 
     # -- general path with the aggregation-multigrid preconditioner ---------------------------------
-    def amg_setup(self, vals, Bv, fp32=True):
+    def amg_setup(self, vals, Bv, fp32=True, levels=None):
         """Per-solve coarse operators (Galerkin sums of the fine values) + the level descriptor array.
         fp32: per-sample matrices also get an fp32 copy of every level's values for the fp32 cycle."""
         p, L = self.p, self.L
         st = _stream(p.device)
         chain = [dict(n=p.n, W=p.W, vals=vals, cols=p.cols)]
-        for lv in p.amg_levels:
+        for lv in (levels if levels is not None else p.amg_levels):
             vc = torch.empty((lv["W"], lv["n"], Bv), dtype=torch.float64, device=p.device)
             _hip.check(L.diffhe_ell_galerkin(_hip.ptr(chain[-1]["vals"]), _hip.ptr(lv["ent_ptr"]), _hip.ptr(lv["contrib"]),
-                                             _hip.ptr(vc), lv["n"], lv["W"], Bv, st), "diffhe_ell_galerkin")
-            chain[-1].update(agg=lv["agg"], agg_ptr=lv["agg_ptr"], agg_members=lv["agg_members"])
+                                             _hip.ptr(lv.get("weights")), _hip.ptr(vc), lv["n"], lv["W"], Bv, st),
+                       "diffhe_ell_galerkin")
+            chain[-1].update(agg=lv["agg"], agg_ptr=lv["agg_ptr"], agg_members=lv["agg_members"],
+                             agg_weights=lv.get("agg_weights"), p_cols=lv.get("p_cols"), p_vals=lv.get("p_vals"))
             chain.append(dict(n=lv["n"], W=lv["W"], vals=vc, cols=lv["cols"]))
         arr = (_hip.AmgLevel * len(chain))()
         for i, lv in enumerate(chain):
@@ -407,6 +409,9 @@ class _Engine:
             if "agg" in lv:
                 arr[i].agg, arr[i].agg_ptr = lv["agg"].data_ptr(), lv["agg_ptr"].data_ptr()
                 arr[i].agg_members = lv["agg_members"].data_ptr()
+                if lv.get("p_cols") is not None:      # smoothed aggregation: P as ELL rows, P^T weights
+                    arr[i].agg_weights, arr[i].p_cols = lv["agg_weights"].data_ptr(), lv["p_cols"].data_ptr()
+                    arr[i].p_vals, arr[i].p_width = lv["p_vals"].data_ptr(), int(lv["p_cols"].shape[0])
         return arr, chain      # keep `chain` alive: it owns the coarse value tensors
 
     def amg_pcg(self, amg, rhs, Bp, Bv, opts):
@@ -684,9 +689,11 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
             rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
         ctx.amg_hier = None
         if solver.method != "ell-jacobi":
-            plan.ensure_amg()
-            if plan.amg_levels:                      # at least one coarse level: aggregation-AMG PCG
-                ctx.amg_hier = eng.amg_setup(vals, Bv, bool(amg.get("fp32", 0)))
+            amg_levels = plan.ensure_amg(smoothed=bool(amg.get("smoothed", 1)))
+            if amg.get("scale") is None:
+                amg["scale"] = 1.3 if amg.get("smoothed", 1) else 1.8
+            if amg_levels:                           # at least one coarse level: aggregation-AMG PCG
+                ctx.amg_hier = eng.amg_setup(vals, Bv, bool(amg.get("fp32", 0)), amg_levels)
         if ctx.amg_hier is not None:
             info.path = "ell-amgpcg"
             x, its, bad, relres = eng.amg_pcg(ctx.amg_hier, rhs, Bp, Bv, amg)
@@ -949,7 +956,7 @@ class DifferentiableFESolver(nn.Module):
     def __init__(self, mesh: FEMesh, kappa: float = 1.0, *, device=None, tol: Optional[float] = None,
                  max_iter: int = 20000, check_every: int = 25, assembly: str = "gather", method: str = "auto",
                  mg: Optional[dict] = None, chain: str = "reference", warm_start=False, reaction: float = 0.0,
-                 operator: str = "auto"):
+                 operator: str = "auto", amg: Optional[dict] = None):
         super().__init__()
         self.mesh = mesh
         if isinstance(kappa, (int, float)):
@@ -1005,10 +1012,15 @@ class DifferentiableFESolver(nn.Module):
         # max_iter: this cycle's iteration counts grow with coefficient contrast and element anisotropy (78 on a benign
         # 84k-node mesh, 4467 on an 86k-node one with an iid e^-4..e^4 field per sample and 6:1 elements, randomised sweep
         # seed 802 case 6) but the CG keeps converging; a cap of 2000 left that case at 2e-9.
-        self.amg = dict(n_coarse=16, gamma=1, scale=1.8, fp32=0, max_iter=20000)
+        # smoothed = 1 (round 3): smoothed aggregation -- the prolongation of the same aggregates smoothed by one damped
+        # Jacobi step of the unit-kappa operator (batch-shared), coarse operators as weighted Galerkin sums per sample:
+        # about half the iterations of the piecewise-constant hierarchy (512^2 through this path: 82 -> see DESIGN);
+        # scale None = 1.3 smoothed / 1.8 piecewise constant
+        self.amg = dict(n_coarse=16, gamma=1, scale=None, fp32=0, max_iter=20000, smoothed=1)
         for item in filter(None, os.environ.get("DIFFHE_AMG", "").split(",")):  # e.g. "scale=1.0,gamma=2,max_iter=20000"
             key, val = item.split("=")
             self.amg[key] = float(val) if key == "scale" else int(val)
+        self.amg.update(amg or {})
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)

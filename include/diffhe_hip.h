@@ -190,11 +190,20 @@ typedef struct diffhe_amg_level {
   const int* agg_ptr;      /* (n_next + 1) CSR of the members of each next-level node; NULL on the last level */
   const int* agg_members;  /* node ids, grouped by aggregate */
   const float* vals32;     /* optional fp32 copy of vals, read by the fp32 cycle when Bv == Bp (may be NULL) */
+  /* SMOOTHED aggregation (ABI v6; all NULL / 0 = piecewise-constant aggregation as above): the batch-shared
+   * prolongation P = (I - omega D_1^-1 A_1) P_0 to the NEXT level, as ELL rows, and its transpose as weights of the
+   * CSR above (agg_ptr / agg_members then list the support of each next-level node's column of P) */
+  const double* agg_weights; /* (nnz P) weight of each entry of agg_members */
+  const int* p_cols;         /* (p_width, n) next-level node of each entry of P's row, -1 = none */
+  const double* p_vals;      /* (p_width, n) */
+  int p_width;
+  int reserved;
 } diffhe_amg_level;
 
-/* vals_coarse[(k*n_coarse + I)*Bv + b] = sum of vals_fine[contrib[c]*Bv + b], c in ent_ptr[k*n_coarse+I] .. */
-int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, double* vals_coarse,
-                        int n_coarse, int W_coarse, int Bv, void* stream);
+/* vals_coarse[(k*n_coarse + I)*Bv + b] = sum of weights[c] * vals_fine[contrib[c]*Bv + b], c in ent_ptr[k*n_coarse+I] ..
+ * (weights NULL = 1: piecewise-constant aggregation; smoothed aggregation: weights[c] = P_iI P_jJ, ABI v6) */
+int diffhe_ell_galerkin(const double* vals_fine, const int* ent_ptr, const int* contrib, const double* weights,
+                        double* vals_coarse, int n_coarse, int W_coarse, int Bv, void* stream);
 /* Batched CG preconditioned by one aggregation-multigrid cycle: V(2,2) Chebyshev-weighted Jacobi,
  * `gamma` coarse corrections per level (2 = W-cycle), coarse correction scaled by `scale`, n_coarse
  * sweeps on the last level.  Replaces torch.linalg.solve (solver.py:174) on general meshes.

@@ -380,3 +380,52 @@ def test_gather_codes_refuse_meshes_beyond_int32():
     with pytest.raises(ValueError, match="int32 gather lists"):
         P._build_dia_pattern_sorted(8192, 2049)
     P._check_gather_code_range(2 * 4096 * 4095)
+
+
+def test_smoothed_aggregation_hierarchy_reproduces_the_galerkin_products():
+    """diffhe.amg.build_hierarchy_sa: the weighted gather lists give P^T A_b P of a PER-SAMPLE matrix (same pattern, other
+    values) to rounding, P^T as CSR is the transpose of P as ELL rows, Dirichlet rows interpolate nothing."""
+    import scipy.sparse as sp
+    from diffhe import amg
+    nodes, el, bn, bv = orc.mesh_rectangle(40, 36)
+    rng = np.random.default_rng(0)
+    n = len(nodes)
+    isbc = np.zeros(n, dtype=bool)
+    isbc[bn] = True
+    nodes = nodes + np.where(isbc[:, None], 0.0, rng.uniform(-0.2, 0.2, nodes.shape) / 40)
+    pat = build_ell_pattern(el, n)
+    cols = pat["cols"]
+
+    def eliminated(kappa):
+        K, _ = orc.assemble_sparse(nodes, el, kappa, np.ones(n))
+        D = sp.diags((~isbc).astype(float))
+        return sp.csr_matrix(D @ K @ D + sp.diags(isbc.astype(float)))
+
+    def ell_values(A, c):
+        W, nn = c.shape
+        v = np.zeros((W, nn))
+        for k in range(W):
+            real = (k == 0) | (c[k] != np.arange(nn))
+            v[k, real] = np.asarray(A[np.arange(nn)[real], c[k][real]]).ravel()
+        return v
+
+    levels = amg.build_hierarchy_sa(cols, ell_values(eliminated(1.0), cols), isbc)
+    assert len(levels) >= 2 and levels[0]["n"] < 0.2 * n
+    Ab = eliminated(np.exp(0.5 * rng.standard_normal(len(el))))
+    vals_f, A = ell_values(Ab, cols).ravel(), Ab
+    for lev in levels:
+        nc, Wc = lev["n"], lev["W"]
+        pw, nf = lev["p_cols"].shape
+        ok = lev["p_cols"].ravel() >= 0
+        P = sp.csr_matrix((lev["p_vals"].ravel()[ok], (np.tile(np.arange(nf), pw)[ok], lev["p_cols"].ravel()[ok])), shape=(nf, nc))
+        if lev is levels[0]:
+            assert abs(P[np.nonzero(isbc)[0]]).sum() == 0.0
+        vc = np.zeros(Wc * nc)
+        np.add.at(vc, np.repeat(np.arange(Wc * nc), np.diff(lev["ent_ptr"])), lev["weights"] * vals_f[lev["contrib"]])
+        Ac = sp.csr_matrix(P.T @ A @ P)
+        ref = ell_values(Ac, lev["cols"]).ravel()
+        assert np.max(np.abs(vc - ref)) <= 1e-13 * np.max(np.abs(ref))
+        PT = sp.csr_matrix((lev["agg_weights"], lev["agg_members"], lev["agg_ptr"]), shape=(nc, nf))
+        assert abs(PT - P.T).max() == 0.0
+        assert np.array_equal(lev["cols"][0], np.arange(nc))           # slot 0 = diagonal
+        vals_f, A = vc, Ac

@@ -402,3 +402,48 @@ def test_element_major_kappa_fields_in_node_layout():
     (u ** 2).sum().backward()
     assert kap.grad.shape == (m, B)
     assert torch.equal(u.detach().t(), u_s) and torch.equal(kap.grad.t(), gk_s) and torch.equal(f_nm.grad.t(), gf_s)
+
+
+# ---- general path: smoothed aggregation -------------------------------------------------------------------------------------
+def test_smoothed_aggregation_halves_the_iterations_of_the_general_path():
+    """method='ell' (any mesh): the smoothed-aggregation hierarchy (default) against the piecewise-constant one
+    (amg={'smoothed': 0}) on a jittered, renumbered mesh with one kappa per sample and a per-element field per sample:
+    same answers (both meet the oracle), about half the iterations."""
+    mesh = _unstructured(96, 88, seed=1)
+    B, n, m = 16, mesh.n_nodes, mesh.n_elements
+    gen = torch.Generator().manual_seed(5)
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for kappa in (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64), torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))):
+        sa = _run(mesh, kappa, f)
+        pc = _run(mesh, kappa, f, amg=dict(smoothed=0))
+        assert sa[3].path == "ell-amgpcg" and sa[3].not_converged == 0 and pc[3].not_converged == 0
+        print(f"general path, {n} nodes: iterations {pc[3].iterations}+{pc[3].adj_iterations} piecewise constant -> "
+              f"{sa[3].iterations}+{sa[3].adj_iterations} smoothed")
+        assert sa[3].iterations <= 0.7 * pc[3].iterations
+        for a, b in zip(sa[:3], pc[:3]):
+            assert float((a - b).abs().max() / b.abs().max()) < 2e-11
+        kb = float(kappa[0]) if kappa.dim() == 1 else kappa[0].numpy()
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[0].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=1)
+        assert rel_err(sa[0][0].cpu().numpy(), uo) < RTOL_U and rel_err(sa[2][0].cpu().numpy(), df) < RTOL_GRAD
+
+
+@pytest.mark.timeout(600)
+def test_general_path_at_512_takes_at_most_45_iterations():
+    """rectangle(512, 512) forced through the general ELL path (method='ell'), 64 samples."""
+    mesh = FEMesh.rectangle(512, 512)
+    B = 64
+    gen = torch.Generator().manual_seed(2024)
+    kappa = (0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)).to(DEV)
+    f = torch.ones(B, mesh.n_nodes, dtype=T64, device=DEV)
+    solver = DifferentiableFESolver(mesh, kappa, device=DEV, method="ell")
+    with torch.no_grad():
+        u = solver(f)
+    info = solver.last_info
+    print(f"512^2 through the general path: {info.iterations} iterations, max relres {info.max_relres:.1e}")
+    assert info.path == "ell-amgpcg" and info.not_converged == 0 and info.iterations <= 45
+    lat = DifferentiableFESolver(mesh, kappa, device=DEV)
+    with torch.no_grad():
+        u2 = lat(f)
+    assert float((u - u2).abs().max() / u2.abs().max()) < 1e-10
