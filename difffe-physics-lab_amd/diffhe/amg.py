@@ -209,16 +209,14 @@ def smoothed_level(A1, ell_index_f, cols_f, active, seed, omega=2.0 / 3.0, drop=
         P.data[np.abs(P.data) < drop] = 0.0
     P.eliminate_zeros()
     P.sort_indices()
-    Ac = (P.T @ A1 @ P).tocsr()
-    Ac.sort_indices()
-    cols_c, ell_index_c = _csr_to_ell(Ac)
-    Wc = cols_c.shape[0]
-    # --- weighted Galerkin gather lists: coarse entry (I, J) = sum over fine nonzeros (i, j) of P_iI a_ij P_jJ ---
+    # --- weighted Galerkin gather lists: coarse entry (I, J) = sum over fine nonzeros (i, j) of P_iI a_ij P_jJ.  The
+    # coarse PATTERN is the set of (I, J) these lists reach (structural: a fine entry whose unit value happens to be
+    # exactly 0 -- the quad diagonal of a right-angled lattice -- still carries a per-sample value) ---
     fi = np.repeat(np.arange(nf, dtype=np.int64), np.diff(A1.indptr))
     fj = A1.indices.astype(np.int64)
     pn = np.diff(P.indptr).astype(np.int64)
     keep = (pn[fi] > 0) & (pn[fj] > 0)
-    fi, fj, fe = fi[keep], fj[keep], ell_index_f[keep]
+    fi, fj, fe, fa = fi[keep], fj[keep], ell_index_f[keep], A1.data[keep]
     ca = pn[fi]                                                    # expand over the nonzeros of P's row i ...
     t1 = np.repeat(np.arange(len(fi)), ca)
     a_loc = np.arange(len(t1)) - np.repeat(np.cumsum(ca) - ca, ca)
@@ -230,11 +228,19 @@ def smoothed_level(A1, ell_index_f, cols_f, active, seed, omega=2.0 / 3.0, drop=
     I, J = P.indices[pa[t2]].astype(np.int64), P.indices[pb].astype(np.int64)
     w = P.data[pa[t2]] * P.data[pb]
     fine_entry = fe[t1[t2]]
-    # coarse ELL entry of (I, J): binary search in the sorted CSR keys of Ac
-    crow = np.repeat(np.arange(nc, dtype=np.int64), np.diff(Ac.indptr))
-    ckey = crow * nc + Ac.indices.astype(np.int64)
-    loc = np.searchsorted(ckey, I * nc + J)
-    assert np.array_equal(ckey[loc], I * nc + J)
+    # coarse unit matrix P^T A_1 P on that pattern (+ a structural diagonal for every coarse node)
+    keys = np.concatenate([I * nc + J, np.arange(nc, dtype=np.int64) * (nc + 1)])
+    data = np.concatenate([w * fa[t1[t2]], np.zeros(nc)])
+    ckey, inv = np.unique(keys, return_inverse=True)
+    cval = np.zeros(len(ckey))
+    np.add.at(cval, inv, data)
+    crow_u = ckey // nc
+    indptr = np.zeros(nc + 1, dtype=np.int64)
+    np.cumsum(np.bincount(crow_u, minlength=nc), out=indptr[1:])
+    Ac = sp.csr_matrix((cval, (ckey % nc).astype(np.int32), indptr), shape=(nc, nc))
+    cols_c, ell_index_c = _csr_to_ell(Ac)
+    Wc = cols_c.shape[0]
+    loc = inv[:len(I)]
     centry = ell_index_c[loc]
     order = np.argsort(centry, kind="stable")
     ent_ptr = np.zeros(Wc * nc + 1, dtype=np.int64)
