@@ -11,7 +11,7 @@ from diffhe import FEMesh, DifferentiableFESolver
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 gammas = [int(sys.argv[3])] if len(sys.argv) > 3 else [1, 2]
-scales = [float(sys.argv[4])] if len(sys.argv) > 4 else [1.8]
+scales = [float(sys.argv[4])] if len(sys.argv) > 4 else [None]   # None: the solver's default (1.3 smoothed, 1.8 piecewise constant)
 m = FEMesh.rectangle(N, N)
 rng = np.random.default_rng(0)
 nodes = m.nodes.numpy().copy()
@@ -25,6 +25,7 @@ for gamma in gammas:
     for scale in scales:
         s = DifferentiableFESolver(mesh, kappa, device="cuda", method="ell")
         s.amg.update(gamma=gamma, scale=scale)
+        print("pass_bytes", mesh.n_nodes * B * 8)
         t0 = time.time(); u = s(f); torch.cuda.synchronize(); t_first = time.time() - t0
         t0 = time.time(); u = s(f); torch.cuda.synchronize(); t = time.time() - t0
         print(f"N={N} B={B} gamma={gamma} scale={scale}: its={s.last_info.iterations} relres={s.last_info.max_relres:.2e} path={s.last_info.path} "

@@ -16,7 +16,10 @@ import sys
 from collections import defaultdict
 
 KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
-        "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel")
+        "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel",
+        "cg_spmv_kernel", "ell_jacobi_kernel", "ell_galerkin_kernel", "ell_residual_out_kernel", "agg_restrict_kernel",
+        "sa_prolong_add_kernel", "amg_update_kernel", "assemble_rows_kernel", "lattice_grad_kappa_kernel",
+        "grad_kappa_shared_kernel")
 
 
 def short(name):
