@@ -862,6 +862,413 @@ __global__ __launch_bounds__(256) void dia_strip2_kernel(Level L, const double* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FUSED two-stage passes of the fp32 V-cycle (batch-shared matrix), round 3.
+//
+// The four strip passes of a level -- first two sweeps, residual + restriction, prolongation + sweep, sweep -- read the
+// right-hand side four times and write / re-read two intermediate iterates: 42 B per node and sample, all of it HBM
+// traffic, at the HBM rate (section 6 of DESIGN.md: these kernels run at 4.4-5.2 TB/s of REAL traffic; their inner
+// loops are not the limit).  The packed-fp32 form leaves most of the issue slots idle, so they are spent on
+// RECOMPUTATION instead: two chained stencil stages per pass, the intermediate iterate kept in registers on a
+// one-column / one-row wider window and never stored.
+//   PRE : x2 = two sweeps from 0, coarse rhs = R (r - A x2)       reads r; writes x2 and the coarse rhs:     9 B  (was 17)
+//   POST: z  = two sweeps on (x2 + P e)                           reads x2, r, e; writes z:                 13 B  (was 25)
+// 22 instead of 42 B per node and sample and cycle.  Same arithmetic per node as the unfused kernels (unit form, packed
+// fp32), evaluated once more on the halo ring; results agree with them to fp32 rounding (different association only).
+// A wave owns its columns for both stages; VT = v2f (two samples per lane) or float (one).
+// ---------------------------------------------------------------------------------------------
+template <typename VT> struct VLane;
+template <> struct VLane<float> {
+  static constexpr int kSpl = 1;
+  static __device__ __forceinline__ float zero() { return 0.0f; }
+  static __device__ __forceinline__ float ld(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ float from_scale(const double* __restrict__ s, unsigned lb) { return s ? (float)s[lb] : 1.0f; }
+  static __device__ __forceinline__ void dot(double& s0, double& s1, float a, float b) { s0 += (double)(a * b); (void)s1; }
+};
+template <> struct VLane<v2f> {
+  static constexpr int kSpl = 2;
+  static __device__ __forceinline__ v2f zero() { return v2f{0.0f, 0.0f}; }
+  static __device__ __forceinline__ v2f ld(rsrc_t r, unsigned voff, unsigned soff) { return bld(r, voff, soff); }
+  static __device__ __forceinline__ v2f from_scale(const double* __restrict__ s, unsigned lb) {
+    return s ? v2f{(float)s[lb], (float)s[lb + 1]} : v2f{1.0f, 1.0f};
+  }
+  static __device__ __forceinline__ void dot(double& s0, double& s1, v2f a, v2f b) {
+    const v2f p = a * b;
+    s0 += (double)p.x;
+    s1 += (double)p.y;
+  }
+};
+
+// K_1 x at the NC columns col0 .. col0 + NC - 1 of grid row R.  xm / xc / xp hold x on rows R - 1 / R / R + 1 at the
+// NC + 2 columns col0 - 1 .. col0 + NC (index j <-> column col0 - 1 + j); out-of-grid positions must hold 0.  Also
+// returns the main diagonal and its reciprocal at those columns.  EDGE: the strip / tile touches a grid edge, so the
+// coefficient indices of non-existent couplings are clamped into the arrays (their values meet a zero x).
+template <typename VT, int NC, int ND, bool EDGE>
+__device__ __forceinline__ void k1_row(const Level& L, int R, int col0, const VT* xm, const VT* xc, const VT* xp, VT* out,
+                                       float* d0, float* rd) {
+  const int W = L.W;
+  const i64 n = L.n;
+  const i64 base = (i64)R * W + col0;
+  auto at = [&](i64 i) -> i64 { return EDGE ? (i < 0 ? 0 : (i > n - 1 ? n - 1 : i)) : i; };
+  const float* __restrict__ v0 = L.v32;
+  const float* __restrict__ v1 = L.v32 + n;
+  const float* __restrict__ v2 = L.v32 + 2 * n;
+  const float* __restrict__ v3 = L.v32 + 3 * n;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const i64 i = base + k;
+    d0[k] = v0[at(i)];
+    rd[k] = L.rd32[at(i)];
+    VT acc = d0[k] * xc[k + 1];
+    acc += v1[at(i)] * xc[k + 2];            // east  (R, c) - (R, c + 1)
+    acc += v1[at(i - 1)] * xc[k];            // west
+    acc += v2[at(i)] * xp[k + 1];            // north (R, c) - (R + 1, c)
+    acc += v2[at(i - W)] * xm[k + 1];        // south
+    if (ND == 4) {
+      acc += v3[at(i)] * xp[k];              // (R, c) - (R + 1, c - 1)
+      acc += v3[at(i - W + 1)] * xm[k + 2];  // (R - 1, c + 1) - (R, c)
+    }
+    out[k] = acc;
+  }
+}
+
+// ---- PRE: first two sweeps from a zero guess + residual + full-weighting restriction -------------------------------
+// Geometry of the F_RESTRICT strips: the wave owns CW coarse columns J0 .. J0 + CW - 1, i.e. the RW = 2 CW + 1 fine
+// residual columns c0w = 2 J0 - 1 .. 2 J0 + 2 CW - 1 (the last one shared with -- and recomputed by -- the next strip),
+// and stores x2 on the first 2 CW of them; tile rows: coarse I0 .. I1 - 1 = fine residual rows r0 .. r1 - 1
+// (r0 = 2 I0 - 1, r1 = 2 I1), x2 stored on rows r0 .. r1 - 2 (all the way up on the last tile).
+template <typename VT, int ND, int CW, bool EDGE>
+__device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, const float* __restrict__ rhs,
+                                               float* __restrict__ x2out, float* __restrict__ crhs, float w0, float w1,
+                                               int cW, const unsigned char* __restrict__ cbc, int Bp, unsigned lb, int c0w,
+                                               int r0, int r1) {
+  constexpr int RW = 2 * CW + 1;
+  constexpr int N1 = RW + 4, N2 = RW + 2;    // columns of the x1 / x2 windows: c0w - 2 + j / c0w - 1 + j
+  const int W = L.W, nyp = L.ny + 1;
+  const VT Z = VLane<VT>::zero();
+  bool ok1[N1];
+  unsigned off1[N1];
+#pragma unroll
+  for (int j = 0; j < N1; ++j) {
+    int c = c0w - 2 + j;
+    ok1[j] = !EDGE || (c >= 0 && c < W);
+    if (EDGE) c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+    off1[j] = 4u * ((unsigned)(c - (c0w - 2) + 2) * (unsigned)Bp + lb);   // base sits two columns further left
+  }
+  // base: element (r0 - 2, c0w - 4): every offset below is non-negative
+  const i64 tile0 = ((i64)(r0 - 2) * W + (c0w - 4)) * Bp;
+  const rsrc_t rr = make_rsrc(rhs + tile0);
+  const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;
+  const float inv_w0 = 1.0f / w0;
+
+  // x1 on grid row R (window N1): w0 rd (r ib); 0 outside the grid
+  auto x1_row = [&](int R, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N1; ++j) dst[j] = Z;
+      return;
+    }
+    const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
+    const i64 rb = (i64)R * W + (c0w - 2);
+#pragma unroll
+    for (int j = 0; j < N1; ++j) {
+      const VT v = VLane<VT>::ld(rr, off1[j], sx);
+      i64 i = rb + j;
+      if (EDGE) i = i < 0 ? 0 : (i > (i64)L.n - 1 ? (i64)L.n - 1 : i);
+      dst[j] = ok1[j] ? (v * ib) * (w0 * L.rd32[i]) : Z;
+    }
+  };
+  // x2 on grid row R (window N2) from x1 rows R - 1, R, R + 1
+  auto x2_row = [&](int R, const VT* am, const VT* ac, const VT* ap, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N2; ++j) dst[j] = Z;
+      return;
+    }
+    VT kx[N2];
+    float d0[N2], rd[N2];
+    k1_row<VT, N2, ND, EDGE>(L, R, c0w - 1, am, ac, ap, kx, d0, rd);
+#pragma unroll
+    for (int j = 0; j < N2; ++j) {
+      const VT bu = ac[j + 1] * (d0[j] * inv_w0);            // x1 = w0 rd bu  ->  bu = x1 d0 / w0
+      const VT v = ac[j + 1] + (w1 * rd[j]) * (bu - kx[j]);
+      dst[j] = ok1[j + 1] ? v : Z;
+    }
+  };
+
+  VT a0[N1], a1[N1], a2[N1];   // x1 rows R - 1, R, R + 1 of the x2 row being formed
+  VT b0[N2], b1[N2], b2[N2];   // x2 rows row - 1, row, row + 1
+  x1_row(r0 - 2, a0);
+  x1_row(r0 - 1, a1);
+  x1_row(r0, a2);
+  x2_row(r0 - 1, a0, a1, a2, b0);
+#pragma unroll
+  for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+  x1_row(r0 + 1, a2);
+  x2_row(r0, a0, a1, a2, b1);
+
+  VT racc[CW], rnext[CW];
+#pragma unroll
+  for (int j = 0; j < CW; ++j) racc[j] = rnext[j] = Z;
+  const int cI0 = (r0 + 1) >> 1, cJ0 = (c0w + 1) >> 1;
+  const int last_store = (r1 >= nyp) ? nyp - 1 : r1 - 2;
+  float* __restrict__ px2 = x2out + ((i64)r0 * W + c0w) * Bp;
+
+  for (int row = r0; row < r1; ++row) {
+    // x1 row + 2 -> x2 row + 1
+#pragma unroll
+    for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+    x1_row(row + 2, a2);
+    x2_row(row + 1, a0, a1, a2, b2);
+    // residual of row `row` on the RW columns c0w .. c0w + RW - 1 (unit form, times s_b at the store)
+    VT kx[RW];
+    float d0[RW], rd[RW];
+    k1_row<VT, RW, ND, EDGE>(L, row, c0w, b0, b1, b2, kx, d0, rd);
+    VT res[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      // bu at (row, c0w + k) from the x1 window kept for this row (a0 after the shift above = x1 row `row`)
+      const VT bu = a0[k + 2] * (d0[k] * inv_w0);
+      res[k] = (!EDGE || (c0w + k >= 0 && c0w + k < W)) ? bu - kx[k] : Z;
+    }
+    // store x2 of this row on the owned columns
+    if (row <= last_store) {
+#pragma unroll
+      for (int k = 0; k < RW - 1; ++k) {
+        if (!EDGE || (c0w + k >= 0 && c0w + k < W)) *(VT*)(px2 + (i64)k * Bp + lb) = b1[k + 1];
+      }
+    }
+    px2 += (i64)W * Bp;
+    // full weighting, as in strip2_body
+    const bool store = (row & 1) || row + 1 >= nyp;
+    if (!(row & 1)) {
+#pragma unroll
+      for (int j = 0; j < CW; ++j) racc[j] += res[2 * j + 1] + 0.5f * (res[2 * j] + res[2 * j + 2]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        racc[j] += 0.5f * (res[2 * j + 1] + res[2 * j]);
+        rnext[j] = 0.5f * (res[2 * j + 1] + res[2 * j + 2]);
+      }
+    }
+    if (store) {
+      const int I = row >> 1;
+      if (I >= cI0) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          const int J = cJ0 + j;
+          if (J < cW) {
+            const i64 Ic = (i64)I * cW + J;
+            *(VT*)(crhs + Ic * Bp + lb) = cbc[Ic] ? Z : sb * racc[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CW; ++j) { racc[j] = rnext[j]; rnext[j] = Z; }
+    }
+#pragma unroll
+    for (int j = 0; j < N2; ++j) { b0[j] = b1[j]; b1[j] = b2[j]; }
+  }
+}
+
+template <typename VT, int ND, int CW>
+__global__ __launch_bounds__(256) void fused_pre_kernel(Level L, const double* __restrict__ scale,
+                                                         const float* __restrict__ rhs, float* __restrict__ x2out,
+                                                         float* __restrict__ crhs, float w0, float w1, int cW,
+                                                         const unsigned char* __restrict__ cbc, int Bp, int ncb, int TR) {
+  constexpr int SPL = VLane<VT>::kSpl;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (SPL * kWave) + SPL * lane;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
+  const int nyp = L.ny + 1;
+  const int J0 = (cb * 4 + wave) * CW, I0 = rc * TR;
+  const int cnyp = (nyp + 1) >> 1;
+  const int I1 = (I0 + TR < cnyp) ? I0 + TR : cnyp;
+  if (!(J0 < cW && I0 < I1)) return;
+  const int c0w = 2 * J0 - 1;
+  const int r0 = I0 > 0 ? 2 * I0 - 1 : 0;
+  const int r1 = (2 * I1 < nyp) ? 2 * I1 : nyp;
+  const VT sb = VLane<VT>::from_scale(scale, lb);
+  const VT ib = 1.0f / sb;
+  constexpr int RW = 2 * CW + 1;
+  // interior tiles: every window column (c0w - 2 .. c0w + RW + 1) and row (r0 - 2 .. r1 + 1) lies inside the grid
+  const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
+  if (edge) fused_pre_body<VT, ND, CW, true>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
+  else fused_pre_body<VT, ND, CW, false>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
+}
+
+// ---- POST: prolongation + correction + both post-smoothing sweeps (+ the partials of rhs . z) ------------------------
+// The wave owns the RW columns c0w .. c0w + RW - 1 (c0w a multiple of RW, even); rows r0 .. r1 - 1.
+template <typename VT, int ND, int RW, bool EDGE, bool DOT>
+__device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const float* __restrict__ xin,
+                                                const float* __restrict__ rhs, const float* __restrict__ ec,
+                                                float* __restrict__ zout, float wA, float wB, int cW, int Bp, unsigned lb,
+                                                int c0w, int r0, int r1, double& s0, double& s1) {
+  constexpr int N1 = RW + 4, N2 = RW + 2;    // x' window: columns c0w - 2 + j; x3 window: c0w - 1 + j
+  constexpr int NCE = RW / 2 + 3;            // coarse columns (c0w - 2) / 2 .. (c0w + RW + 1 + 1) / 2
+  const int W = L.W, nyp = L.ny + 1;
+  const VT Z = VLane<VT>::zero();
+  bool ok1[N1];
+  unsigned off1[N1];
+#pragma unroll
+  for (int j = 0; j < N1; ++j) {
+    int c = c0w - 2 + j;
+    ok1[j] = !EDGE || (c >= 0 && c < W);
+    if (EDGE) c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+    off1[j] = 4u * ((unsigned)(c - (c0w - 2) + 2) * (unsigned)Bp + lb);
+  }
+  const int cj0 = (c0w >> 1) - 1;            // first coarse column of the window (c0w is even)
+  unsigned offc[NCE];
+#pragma unroll
+  for (int j = 0; j < NCE; ++j) {
+    int cj = cj0 + j;
+    cj = cj < 0 ? 0 : (cj > cW - 1 ? cW - 1 : cj);
+    offc[j] = 4u * ((unsigned)cj * (unsigned)Bp + lb);
+  }
+  const i64 tile0 = ((i64)(r0 - 2) * W + (c0w - 4)) * Bp;
+  const rsrc_t rx = make_rsrc(xin + tile0);
+  const rsrc_t rr = make_rsrc(rhs + tile0);
+  const int cr0 = (r0 - 2 > 0 ? r0 - 2 : 0) >> 1;
+  const rsrc_t rc = make_rsrc(ec + (i64)cr0 * cW * Bp);
+  const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp, rowCB = 4u * (unsigned)cW * (unsigned)Bp;
+
+  // x' = x + mask (P e) on grid row R
+  auto xp_row = [&](int R, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N1; ++j) dst[j] = Z;
+      return;
+    }
+    const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
+    const unsigned sc = (unsigned)((R >> 1) - cr0) * rowCB;
+    VT ce[NCE], ce2[NCE];
+#pragma unroll
+    for (int j = 0; j < NCE; ++j) {
+      ce[j] = VLane<VT>::ld(rc, offc[j], sc);
+      ce2[j] = (R & 1) ? VLane<VT>::ld(rc, offc[j], sc + rowCB) : Z;
+    }
+    const i64 rb = (i64)R * W + (c0w - 2);
+#pragma unroll
+    for (int j = 0; j < N1; ++j) {
+      // window column c0w - 2 + j: even j <-> even column (c0w even) <-> coarse column cj0 + j / 2 ... index j / 2 + (1 - 1)
+      VT corr;
+      if (!(j & 1))                      // coarse column (c0w - 2 + j) / 2 = cj0 + j / 2
+        corr = (R & 1) ? 0.5f * (ce[j / 2] + ce2[j / 2]) : ce[j / 2];
+      else                               // between coarse columns cj0 + (j - 1) / 2 and + 1
+        corr = (R & 1) ? 0.5f * (ce[(j + 1) / 2] + ce2[(j - 1) / 2]) : 0.5f * (ce[(j - 1) / 2] + ce[(j + 1) / 2]);
+      i64 i = rb + j;
+      if (EDGE) i = i < 0 ? 0 : (i > (i64)L.n - 1 ? (i64)L.n - 1 : i);
+      const VT v = VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
+      dst[j] = ok1[j] ? v : Z;
+    }
+  };
+  // bu = r / s_b on grid row R at the N2 columns c0w - 1 + j
+  auto bu_row = [&](int R, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N2; ++j) dst[j] = Z;
+      return;
+    }
+    const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
+#pragma unroll
+    for (int j = 0; j < N2; ++j) dst[j] = ok1[j + 1] ? VLane<VT>::ld(rr, off1[j + 1], sx) * ib : Z;
+  };
+  // x3 on grid row R (window N2) from x' rows R - 1, R, R + 1 and bu row R
+  auto x3_row = [&](int R, const VT* am, const VT* ac, const VT* ap, const VT* bu, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N2; ++j) dst[j] = Z;
+      return;
+    }
+    VT kx[N2];
+    float d0[N2], rd[N2];
+    k1_row<VT, N2, ND, EDGE>(L, R, c0w - 1, am, ac, ap, kx, d0, rd);
+#pragma unroll
+    for (int j = 0; j < N2; ++j) {
+      const VT v = ac[j + 1] + (wA * rd[j]) * (bu[j] - kx[j]);
+      dst[j] = ok1[j + 1] ? v : Z;
+    }
+  };
+
+  VT a0[N1], a1[N1], a2[N1];   // x' rows
+  VT b0[N2], b1[N2], b2[N2];   // x3 rows row - 1, row, row + 1
+  VT u1[N2], u2[N2];           // bu rows row, row + 1
+  xp_row(r0 - 2, a0);
+  xp_row(r0 - 1, a1);
+  xp_row(r0, a2);
+  bu_row(r0 - 1, u1);
+  x3_row(r0 - 1, a0, a1, a2, u1, b0);
+#pragma unroll
+  for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+  xp_row(r0 + 1, a2);
+  bu_row(r0, u1);
+  x3_row(r0, a0, a1, a2, u1, b1);
+  float* __restrict__ pz = zout + ((i64)r0 * W + c0w) * Bp;
+
+  for (int row = r0; row < r1; ++row) {
+#pragma unroll
+    for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+    xp_row(row + 2, a2);
+    bu_row(row + 1, u2);
+    x3_row(row + 1, a0, a1, a2, u2, b2);
+    VT kx[RW];
+    float d0[RW], rd[RW];
+    k1_row<VT, RW, ND, EDGE>(L, row, c0w, b0, b1, b2, kx, d0, rd);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      if (EDGE && c0w + k >= W) continue;
+      const VT z = b1[k + 1] + (wB * rd[k]) * (u1[k + 1] - kx[k]);
+      *(VT*)(pz + (i64)k * Bp + lb) = z;
+      if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);     // (r / s_b) . z; times s_b after the loop
+    }
+    pz += (i64)W * Bp;
+#pragma unroll
+    for (int j = 0; j < N2; ++j) { b0[j] = b1[j]; b1[j] = b2[j]; u1[j] = u2[j]; }
+  }
+}
+
+template <typename VT, int ND, int RW, bool DOT>
+__global__ __launch_bounds__(256) void fused_post_kernel(Level L, const double* __restrict__ scale,
+                                                          const float* __restrict__ xin, const float* __restrict__ rhs,
+                                                          const float* __restrict__ ec, float* __restrict__ zout, float wA,
+                                                          float wB, int cW, double* __restrict__ part, int Bp, int ncb,
+                                                          int TR) {
+  __shared__ double lds[4 * kWave];
+  constexpr int SPL = VLane<VT>::kSpl;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (SPL * kWave) + SPL * lane;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
+  const int nyp = L.ny + 1;
+  const int c0w = (cb * 4 + wave) * RW;
+  const int r0 = rc * TR;
+  const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+  const bool active = c0w < L.W && r0 < r1;
+  const VT sb = VLane<VT>::from_scale(scale, lb);
+  const VT ib = 1.0f / sb;
+  double s0 = 0.0, s1 = 0.0;
+  if (active) {
+    const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
+    if (edge) fused_post_body<VT, ND, RW, true, DOT>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+    else fused_post_body<VT, ND, RW, false, DOT>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+  }
+  if (DOT) {
+    const double f0 = scale ? scale[lb] : 1.0;
+    const double t0 = block_sum_per_sample(s0 * f0, Bp, lds);
+    if (wave == 0) part[(i64)blockIdx.x * Bp + lb] = t0;
+    if (SPL == 2) {
+      const double f1 = scale ? scale[lb + 1] : 1.0;
+      const double t1 = block_sum_per_sample(s1 * f1, Bp, lds);
+      if (wave == 0) part[(i64)blockIdx.x * Bp + lb + 1] = t1;
+    }
+  }
+}
+
 constexpr int kStripCols = 8;
 // fp32-stored V-cycle vectors run best on 4-column strips (kernel trace, same box: prolongation + sweep -7 %,
 // first two sweeps -5 % against 8 columns); fp64 vectors keep 8 (half the register footprint per column there)
@@ -973,6 +1380,46 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
   }
 #undef STRIP2B
 #undef STRIP2
+}
+
+// Fused two-stage passes (fused_pre_kernel / fused_post_kernel): DIFFHE_FUSED=0 keeps the four single-stage passes,
+// DIFFHE_FUSED_SPL=1 runs them with one sample per lane
+inline int fused_mode() {
+  static const int on = getenv("DIFFHE_FUSED") ? atoi(getenv("DIFFHE_FUSED")) : 1;
+  static const int spl = getenv("DIFFHE_FUSED_SPL") ? atoi(getenv("DIFFHE_FUSED_SPL")) : 2;
+  return on ? (spl == 1 ? 1 : 2) : 0;
+}
+inline unsigned fused_lds() {
+  static const unsigned v = getenv("DIFFHE_FUSED_LDS") ? (unsigned)atoi(getenv("DIFFHE_FUSED_LDS")) : 40000u;
+  return v;
+}
+
+void launch_fused_pre(const Level& L, const Level& C, const double* scale, const float* rhs, float* x2, float* crhs,
+                      double w0, double w1, int Bp, const StripGeom& g, int spl, hipStream_t st) {
+  constexpr int CW = kRestrictCols;
+  diffhe::account(9.0 * (double)L.n * Bp);   // r read, x2 and the coarse rhs written
+  const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
+#define FPRE(VT_, ND_)                                                                                               \
+  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,     \
+                     (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
+  if (spl == 2) { if (L.nd == 3) FPRE(v2f, 3); else FPRE(v2f, 4); }
+  else { if (L.nd == 3) FPRE(float, 3); else FPRE(float, 4); }
+#undef FPRE
+}
+
+void launch_fused_post(const Level& L, const Level& C, const double* scale, const float* xin, const float* rhs,
+                       const float* ec, float* z, double wA, double wB, double* part, int Bp, const StripGeom& g, int spl,
+                       hipStream_t st) {
+  diffhe::account(13.0 * (double)L.n * Bp);  // x2, r, a quarter of e read; z written
+  const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
+#define FPOST(VT_, ND_, DOT_)                                                                                           \
+  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, z, \
+                     (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+#define FPOSTD(VT_, ND_) do { if (part) FPOST(VT_, ND_, true); else FPOST(VT_, ND_, false); } while (0)
+  if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3); else FPOSTD(v2f, 4); }
+  else { if (L.nd == 3) FPOSTD(float, 3); else FPOSTD(float, 4); }
+#undef FPOSTD
+#undef FPOST
 }
 
 // One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
@@ -1455,6 +1902,7 @@ struct Hier {
   const double* scale;
   double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
   int nu, n_coarse, fmg_coarse_cycles;
+  int fuse;  // 0: four single-stage strip passes per level; 1 / 2: fused two-stage passes, samples per lane
   double coarse_lmax;  // upper bound of the spectrum of D^-1 A on the coarsest level (2 for an M-matrix)
   // per-level work vectors
   void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
@@ -1690,6 +2138,8 @@ template <typename TV>
 TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st, int l0 = 0) {
   const TV* rhs[kMaxLevels];
   TV* cur[kMaxLevels];
+  bool fused[kMaxLevels];
+  StripGeom gpost[kMaxLevels];
   rhs[l0] = rhs0;  // the cycle runs on levels l0 .. last (l0 > 0: inside full multigrid)
   const int last = H.nl - 1;
   for (int l = l0; l <= last; ++l) {  // downward leg
@@ -1704,6 +2154,34 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     const bool only = false;
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
+    fused[l] = false;
+    if (sizeof(TV) == 4 && H.fuse && H.nu == 2 && strip2_ok(L, H.Bv, H.Bp)) {
+      // both sweeps + residual + restriction in ONE pass (fused_pre_kernel); the way up is fused_post_kernel
+      const Level& C = H.lev[l + 1];
+      const int spl = H.fuse;
+      if (L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use) {
+        constexpr int CW = kRestrictCols;
+        StripGeom g{true, 0, 0, 0};
+        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
+        const int gy = H.Bp / (spl * kWave);
+        int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
+        if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+        if (nrc < 1) nrc = 1;
+        g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+        g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+        gpost[l] = strip_geom(L, H.Bp, 4, spl);
+        if (strip2_tile_fits(L, H.Bp, 2 * g.TR + 4) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 3)) {
+          if (l == 0) kp_begin(KP_FIRST2, st);
+          launch_fused_pre(L, C, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0], H.omega[1],
+                           H.Bp, g, spl, st);
+          if (l == 0) kp_end(KP_FIRST2, st);
+          fused[l] = true;
+          cur[l] = a;
+          rhs[l + 1] = (const TV*)H.rhs[l + 1];
+          continue;
+        }
+      }
+    }
     int done;
     if (sweeps >= 2) {
       TV* resu;
@@ -1765,6 +2243,16 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     const Level& C = H.lev[l + 1];
     TV* a = cur[l];
     TV* b2 = (a == (TV*)H.xa[l]) ? (TV*)H.xb[l] : (TV*)H.xa[l];
+    if (fused[l]) {   // prolongation + correction + both post-sweeps (+ the partials of rhs . z) in ONE pass
+      const bool dot = (l == l0) && rz_part;
+      if (l == 0) kp_begin(KP_PROLONG, st);
+      launch_fused_post(L, C, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
+                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.fuse, st);
+      if (l == 0) kp_end(KP_PROLONG, st);
+      if (dot && rz_blocks) *rz_blocks = gpost[l].ncb * gpost[l].nrc;
+      cur[l] = b2;
+      continue;
+    }
     int s0 = 0;
     StripGeom g;
     const bool two = strip2_pick<TV>(L, H.Bv, H.Bp, strip_cols<TV>(), &g);
@@ -1882,6 +2370,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
+  H.fuse = fused_mode();
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
 }
@@ -1936,6 +2425,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const bool use_fmg = (precond_fp32 & 2) != 0 && H.nl > 1;
   const bool warm = (precond_fp32 & 32) != 0;   // x holds an initial guess (e.g. the previous step of an optimisation)
   H.fmg_coarse_cycles = 1 + ((precond_fp32 >> 2) & 3);
+  if (precond_fp32 & 64) H.fuse = 0;             // bit 6: keep the four single-stage passes (A/B runs, tests)
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;

@@ -277,6 +277,8 @@ typedef struct diffhe_mg_level {
  *            bits 2-3: extra V-cycles per coarse level of that start (0..3);
  *            bit 5: WARM START -- `x` holds an initial guess on entry (the previous solution of an optimisation
  *            loop): the solve starts from x + FMG(b - A x) (bit 1 set) or from x itself;
+ *            bit 6: keep the four single-stage strip passes per level in the fp32 V-cycle of a batch-shared matrix
+ *            (default: the fused two-stage passes, 22 instead of 42 B per node and sample and cycle);
  *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at
  *            |r| <= max(tol |b|, 0.5 u |A_b| |x0_b|), u = 2^-53, |A_b| = 2 scale[b] max_i K_ii: fp64 cannot
  *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the
