@@ -453,12 +453,22 @@ KERNEL_NAMES = ["fused CG step: p = z + beta p, Ap = A p, p.Ap (x formed at the 
                 "Jacobi sweep"]
 
 
-def kernel_table(kprof, n, Bp, f32):
+KERNEL_NAMES_FUSED = [KERNEL_NAMES[0], KERNEL_NAMES[1],
+                      "fused PRE pass: two sweeps from 0 + residual + restriction (x2 and the coarse rhs written; 9 B)",
+                      KERNEL_NAMES[3],
+                      "fused POST pass: prolongation + correction + both post-sweeps (+ r.z partials; 13 B)",
+                      KERNEL_NAMES[5]]
+
+
+def kernel_table(kprof, n, Bp, f32, fused=False):
     """Per-kernel roofline rows from the in-solver HIP-event totals (fine level, forward solves)."""
     tv = 4.0 if f32 else 8.0
     bytes_ = [(3 * tv + 8.0), 24.0 + (4.0 if f32 else 0.0), 2.0 * tv, 2.25 * tv, 3.25 * tv, 3.0 * tv]
+    names = KERNEL_NAMES
+    if fused and f32:
+        bytes_[2], bytes_[4], names = 9.0, 13.0, KERNEL_NAMES_FUSED
     rows = []
-    for nm, bpn, (ms_, n_) in zip(KERNEL_NAMES, bytes_, kprof):
+    for nm, bpn, (ms_, n_) in zip(names, bytes_, kprof):
         if n_ > 0:
             avg = ms_ * 1e-3 / n_
             byt = bpn * n * Bp
@@ -532,7 +542,7 @@ def variant_config2(args, torch, L, _hip, ctypes, dev, timed):
 
 
 def _lattice_variant_roofline(L, ctypes, n, Bp, f32):
-    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32)
+    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0)
     if not rows:
         return None
     top = dict(rows[0])
@@ -677,6 +687,10 @@ KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, f
                        "dia_strip_kernel<float, float, double, 2, 0, 3, true, false, 4, 1>"]
 
 
+KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2>",
+                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true>", KERNEL_SYMBOLS_FP32[5]]
+
+
 def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, prof_n, kprof=()):
     """Roofline entry of the dominant kernel: algorithmic bytes per launch / its average duration in the solver."""
     from diffhe.plan import padded_batch
@@ -686,11 +700,14 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     if not (path == "lattice-mgpcg" and args.kappa == "sample" and Bp >= 64 and N >= 191 and len(kprof) == 6):
         return None
     f32 = bool(solver.mg.get("fp32"))
-    table = kernel_table(kprof, n, Bp, f32)
+    fused = bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0 and bool(solver.mg.get("fused", 1))
+    table = kernel_table(kprof, n, Bp, f32, fused)
     if not table:
         return None
-    traffic, src = pmc_traffic(KERNEL_SYMBOLS_FP32, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")
-    by_name = dict(zip(KERNEL_NAMES, KERNEL_SYMBOLS_FP32))
+    symbols = KERNEL_SYMBOLS_FUSED if fused else KERNEL_SYMBOLS_FP32
+    have = [sy for sy, (ms_, n_) in zip(symbols, kprof) if n_ > 0]
+    traffic, src = pmc_traffic(have, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")
+    by_name = dict(zip(KERNEL_NAMES_FUSED if fused else KERNEL_NAMES, symbols))
     for row in table:
         row["symbol"] = by_name[row["kernel"]] if f32 else None
         row["traffic"] = traffic.get(row["symbol"]) if f32 else None

@@ -901,36 +901,78 @@ template <> struct VLane<v2f> {
   }
 };
 
-// K_1 x at the NC columns col0 .. col0 + NC - 1 of grid row R.  xm / xc / xp hold x on rows R - 1 / R / R + 1 at the
-// NC + 2 columns col0 - 1 .. col0 + NC (index j <-> column col0 - 1 + j); out-of-grid positions must hold 0.  Also
-// returns the main diagonal and its reciprocal at those columns.  EDGE: the strip / tile touches a grid edge, so the
-// coefficient indices of non-existent couplings are clamped into the arrays (their values meet a zero x).
-template <typename VT, int NC, int ND, bool EDGE>
-__device__ __forceinline__ void k1_row(const Level& L, int R, int col0, const VT* xm, const VT* xc, const VT* xp, VT* out,
-                                       float* d0, float* rd) {
-  const int W = L.W;
-  const i64 n = L.n;
+// Where the matrix coefficients of the fused passes come from.
+//   SHARED: batch-shared fp32 copies + reciprocal diagonal, wave-uniform scalar loads (values are plain floats);
+//   per sample: fp32 diagonal + scaled fp16 off-diagonals (Level.v32 / o16 / oscale), one value per sample and lane,
+//   buffer loads with tile-relative offsets; the reciprocal diagonal is v_rcp_f32 of the loaded diagonal.
+template <typename VT, bool SHARED> struct Coef;
+template <typename VT> struct Coef<VT, true> {
+  typedef float T;
+  const float *v0, *v1, *v2, *v3, *rdp;
+  __device__ __forceinline__ Coef(const Level& L, i64, unsigned, int) : v0(L.v32), v1(L.v32 + L.n), v2(L.v32 + 2 * (i64)L.n),
+                                                                        v3(L.v32 + 3 * (i64)L.n), rdp(L.rd32) {}
+  __device__ __forceinline__ T d(i64 i) const { return v0[i]; }
+  __device__ __forceinline__ T e(i64 i) const { return v1[i]; }
+  __device__ __forceinline__ T n2(i64 i) const { return v2[i]; }
+  __device__ __forceinline__ T q3(i64 i) const { return v3[i]; }
+  __device__ __forceinline__ T rd(i64 i, T) const { return rdp[i]; }
+};
+__device__ __forceinline__ float ldh(rsrc_t r, unsigned voff, float) {
+  return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0));
+}
+__device__ __forceinline__ v2f ldh(rsrc_t r, unsigned voff, v2f) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+  return v2f{(float)h.x, (float)h.y};
+}
+template <typename VT> struct Coef<VT, false> {
+  typedef VT T;
+  rsrc_t r0, r1, r2, r3;
+  i64 base;       // node index the resources are based at (<= every index the tile touches)
+  unsigned lb, Bp;
+  float osc;
+  __device__ __forceinline__ Coef(const Level& L, i64 base_, unsigned lb_, int Bp_)
+      : base(base_), lb(lb_), Bp((unsigned)Bp_), osc((float)L.oscale) {
+    const i64 n = L.n;
+    r0 = make_rsrc(L.v32 + base * Bp_);
+    r1 = make_rsrc(L.o16 + base * Bp_);
+    r2 = make_rsrc(L.o16 + (n + base) * Bp_);
+    r3 = make_rsrc(L.o16 + (2 * n + base) * Bp_);
+  }
+  __device__ __forceinline__ unsigned off(i64 i) const { return (unsigned)(i - base) * Bp + lb; }
+  __device__ __forceinline__ T d(i64 i) const { return VLane<VT>::ld(r0, 4u * off(i), 0u); }
+  __device__ __forceinline__ T e(i64 i) const { return osc * ldh(r1, 2u * off(i), VT{}); }
+  __device__ __forceinline__ T n2(i64 i) const { return osc * ldh(r2, 2u * off(i), VT{}); }
+  __device__ __forceinline__ T q3(i64 i) const { return osc * ldh(r3, 2u * off(i), VT{}); }
+  __device__ __forceinline__ T rd(i64, T dv) const { return 1.0f / dv; }
+};
+
+// K_1 x at the NC columns col0 .. col0 + NC - 1 of grid row R, handed column by column to `use(k, K1x, d0, rd)`.
+// xm / xc / xp hold x on rows R - 1 / R / R + 1 at the NC + 2 columns col0 - 1 .. col0 + NC (index j <-> column
+// col0 - 1 + j); out-of-grid positions must hold 0.  EDGE: the strip / tile touches a grid edge, so the coefficient
+// indices of non-existent couplings are clamped into the arrays (their values meet a zero x).
+template <typename VT, int NC, int ND, bool EDGE, typename CF, typename F>
+__device__ __forceinline__ void k1_row(const CF& cf, i64 n, int W, int R, int col0, const VT* xm, const VT* xc,
+                                       const VT* xp, F&& use) {
   const i64 base = (i64)R * W + col0;
   auto at = [&](i64 i) -> i64 { return EDGE ? (i < 0 ? 0 : (i > n - 1 ? n - 1 : i)) : i; };
-  const float* __restrict__ v0 = L.v32;
-  const float* __restrict__ v1 = L.v32 + n;
-  const float* __restrict__ v2 = L.v32 + 2 * n;
-  const float* __restrict__ v3 = L.v32 + 3 * n;
+  typename CF::T ew = cf.e(at(base - 1));       // west coupling of the first column; then carried along the row
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const i64 i = base + k;
-    d0[k] = v0[at(i)];
-    rd[k] = L.rd32[at(i)];
-    VT acc = d0[k] * xc[k + 1];
-    acc += v1[at(i)] * xc[k + 2];            // east  (R, c) - (R, c + 1)
-    acc += v1[at(i - 1)] * xc[k];            // west
-    acc += v2[at(i)] * xp[k + 1];            // north (R, c) - (R + 1, c)
-    acc += v2[at(i - W)] * xm[k + 1];        // south
+    const typename CF::T d0 = cf.d(at(i));
+    const typename CF::T ee = cf.e(at(i));
+    VT acc = d0 * xc[k + 1];
+    acc += ee * xc[k + 2];                       // east  (R, c) - (R, c + 1)
+    acc += ew * xc[k];                           // west
+    acc += cf.n2(at(i)) * xp[k + 1];             // north (R, c) - (R + 1, c)
+    acc += cf.n2(at(i - W)) * xm[k + 1];         // south
     if (ND == 4) {
-      acc += v3[at(i)] * xp[k];              // (R, c) - (R + 1, c - 1)
-      acc += v3[at(i - W + 1)] * xm[k + 2];  // (R - 1, c + 1) - (R, c)
+      acc += cf.q3(at(i)) * xp[k];               // (R, c) - (R + 1, c - 1)
+      acc += cf.q3(at(i - W + 1)) * xm[k + 2];   // (R - 1, c + 1) - (R, c)
     }
-    out[k] = acc;
+    use(k, acc, d0, cf.rd(at(i), d0));
+    ew = ee;
   }
 }
 
@@ -939,7 +981,7 @@ __device__ __forceinline__ void k1_row(const Level& L, int R, int col0, const VT
 // residual columns c0w = 2 J0 - 1 .. 2 J0 + 2 CW - 1 (the last one shared with -- and recomputed by -- the next strip),
 // and stores x2 on the first 2 CW of them; tile rows: coarse I0 .. I1 - 1 = fine residual rows r0 .. r1 - 1
 // (r0 = 2 I0 - 1, r1 = 2 I1), x2 stored on rows r0 .. r1 - 2 (all the way up on the last tile).
-template <typename VT, int ND, int CW, bool EDGE>
+template <typename VT, int ND, int CW, bool EDGE, bool SHARED>
 __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, const float* __restrict__ rhs,
                                                float* __restrict__ x2out, float* __restrict__ crhs, float w0, float w1,
                                                int cW, const unsigned char* __restrict__ cbc, int Bp, unsigned lb, int c0w,
@@ -947,7 +989,12 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
   constexpr int RW = 2 * CW + 1;
   constexpr int N1 = RW + 4, N2 = RW + 2;    // columns of the x1 / x2 windows: c0w - 2 + j / c0w - 1 + j
   const int W = L.W, nyp = L.ny + 1;
+  const i64 n = L.n;
   const VT Z = VLane<VT>::zero();
+  typedef Coef<VT, SHARED> CF;
+  i64 cbase = (i64)(r0 - 3) * W;             // coefficient resources: based below everything the tile touches
+  if (cbase < 0) cbase = 0;
+  const CF cf(L, cbase, lb, Bp);
   bool ok1[N1];
   unsigned off1[N1];
 #pragma unroll
@@ -976,8 +1023,9 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
     for (int j = 0; j < N1; ++j) {
       const VT v = VLane<VT>::ld(rr, off1[j], sx);
       i64 i = rb + j;
-      if (EDGE) i = i < 0 ? 0 : (i > (i64)L.n - 1 ? (i64)L.n - 1 : i);
-      dst[j] = ok1[j] ? (v * ib) * (w0 * L.rd32[i]) : Z;
+      if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+      const typename CF::T dv = SHARED ? typename CF::T{} : cf.d(i);
+      dst[j] = ok1[j] ? (v * ib) * (w0 * cf.rd(i, dv)) : Z;
     }
   };
   // x2 on grid row R (window N2) from x1 rows R - 1, R, R + 1
@@ -987,15 +1035,11 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
       for (int j = 0; j < N2; ++j) dst[j] = Z;
       return;
     }
-    VT kx[N2];
-    float d0[N2], rd[N2];
-    k1_row<VT, N2, ND, EDGE>(L, R, c0w - 1, am, ac, ap, kx, d0, rd);
-#pragma unroll
-    for (int j = 0; j < N2; ++j) {
-      const VT bu = ac[j + 1] * (d0[j] * inv_w0);            // x1 = w0 rd bu  ->  bu = x1 d0 / w0
-      const VT v = ac[j + 1] + (w1 * rd[j]) * (bu - kx[j]);
+    k1_row<VT, N2, ND, EDGE>(cf, n, W, R, c0w - 1, am, ac, ap, [&](int j, VT kx, typename CF::T d0, typename CF::T rd) {
+      const VT bu = ac[j + 1] * (d0 * inv_w0);              // x1 = w0 rd bu  ->  bu = x1 d0 / w0
+      const VT v = ac[j + 1] + (w1 * rd) * (bu - kx);
       dst[j] = ok1[j + 1] ? v : Z;
-    }
+    });
   };
 
   VT a0[N1], a1[N1], a2[N1];   // x1 rows R - 1, R, R + 1 of the x2 row being formed
@@ -1023,16 +1067,12 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
     x1_row(row + 2, a2);
     x2_row(row + 1, a0, a1, a2, b2);
     // residual of row `row` on the RW columns c0w .. c0w + RW - 1 (unit form, times s_b at the store)
-    VT kx[RW];
-    float d0[RW], rd[RW];
-    k1_row<VT, RW, ND, EDGE>(L, row, c0w, b0, b1, b2, kx, d0, rd);
     VT res[RW];
-#pragma unroll
-    for (int k = 0; k < RW; ++k) {
+    k1_row<VT, RW, ND, EDGE>(cf, n, W, row, c0w, b0, b1, b2, [&](int k, VT kx, typename CF::T d0, typename CF::T) {
       // bu at (row, c0w + k) from the x1 window kept for this row (a0 after the shift above = x1 row `row`)
-      const VT bu = a0[k + 2] * (d0[k] * inv_w0);
-      res[k] = (!EDGE || (c0w + k >= 0 && c0w + k < W)) ? bu - kx[k] : Z;
-    }
+      const VT bu = a0[k + 2] * (d0 * inv_w0);
+      res[k] = (!EDGE || (c0w + k >= 0 && c0w + k < W)) ? bu - kx : Z;
+    });
     // store x2 of this row on the owned columns
     if (row <= last_store) {
 #pragma unroll
@@ -1073,7 +1113,7 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
   }
 }
 
-template <typename VT, int ND, int CW>
+template <typename VT, int ND, int CW, bool SHARED>
 __global__ __launch_bounds__(256) void fused_pre_kernel(Level L, const double* __restrict__ scale,
                                                          const float* __restrict__ rhs, float* __restrict__ x2out,
                                                          float* __restrict__ crhs, float w0, float w1, int cW,
@@ -1097,13 +1137,13 @@ __global__ __launch_bounds__(256) void fused_pre_kernel(Level L, const double* _
   constexpr int RW = 2 * CW + 1;
   // interior tiles: every window column (c0w - 2 .. c0w + RW + 1) and row (r0 - 2 .. r1 + 1) lies inside the grid
   const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
-  if (edge) fused_pre_body<VT, ND, CW, true>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
-  else fused_pre_body<VT, ND, CW, false>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
+  if (edge) fused_pre_body<VT, ND, CW, true, SHARED>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
+  else fused_pre_body<VT, ND, CW, false, SHARED>(L, ib, sb, rhs, x2out, crhs, w0, w1, cW, cbc, Bp, lb, c0w, r0, r1);
 }
 
 // ---- POST: prolongation + correction + both post-smoothing sweeps (+ the partials of rhs . z) ------------------------
 // The wave owns the RW columns c0w .. c0w + RW - 1 (c0w a multiple of RW, even); rows r0 .. r1 - 1.
-template <typename VT, int ND, int RW, bool EDGE, bool DOT>
+template <typename VT, int ND, int RW, bool EDGE, bool DOT, bool SHARED>
 __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const float* __restrict__ xin,
                                                 const float* __restrict__ rhs, const float* __restrict__ ec,
                                                 float* __restrict__ zout, float wA, float wB, int cW, int Bp, unsigned lb,
@@ -1111,7 +1151,12 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   constexpr int N1 = RW + 4, N2 = RW + 2;    // x' window: columns c0w - 2 + j; x3 window: c0w - 1 + j
   constexpr int NCE = RW / 2 + 3;            // coarse columns (c0w - 2) / 2 .. (c0w + RW + 1 + 1) / 2
   const int W = L.W, nyp = L.ny + 1;
+  const i64 n = L.n;
   const VT Z = VLane<VT>::zero();
+  typedef Coef<VT, SHARED> CF;
+  i64 cbase = (i64)(r0 - 3) * W;
+  if (cbase < 0) cbase = 0;
+  const CF cf(L, cbase, lb, Bp);
   bool ok1[N1];
   unsigned off1[N1];
 #pragma unroll
@@ -1154,14 +1199,13 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     const i64 rb = (i64)R * W + (c0w - 2);
 #pragma unroll
     for (int j = 0; j < N1; ++j) {
-      // window column c0w - 2 + j: even j <-> even column (c0w even) <-> coarse column cj0 + j / 2 ... index j / 2 + (1 - 1)
       VT corr;
-      if (!(j & 1))                      // coarse column (c0w - 2 + j) / 2 = cj0 + j / 2
+      if (!(j & 1))                      // even window column <-> coarse column cj0 + j / 2
         corr = (R & 1) ? 0.5f * (ce[j / 2] + ce2[j / 2]) : ce[j / 2];
       else                               // between coarse columns cj0 + (j - 1) / 2 and + 1
         corr = (R & 1) ? 0.5f * (ce[(j + 1) / 2] + ce2[(j - 1) / 2]) : 0.5f * (ce[(j - 1) / 2] + ce[(j + 1) / 2]);
       i64 i = rb + j;
-      if (EDGE) i = i < 0 ? 0 : (i > (i64)L.n - 1 ? (i64)L.n - 1 : i);
+      if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
       const VT v = VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
       dst[j] = ok1[j] ? v : Z;
     }
@@ -1184,14 +1228,10 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
       for (int j = 0; j < N2; ++j) dst[j] = Z;
       return;
     }
-    VT kx[N2];
-    float d0[N2], rd[N2];
-    k1_row<VT, N2, ND, EDGE>(L, R, c0w - 1, am, ac, ap, kx, d0, rd);
-#pragma unroll
-    for (int j = 0; j < N2; ++j) {
-      const VT v = ac[j + 1] + (wA * rd[j]) * (bu[j] - kx[j]);
+    k1_row<VT, N2, ND, EDGE>(cf, n, W, R, c0w - 1, am, ac, ap, [&](int j, VT kx, typename CF::T, typename CF::T rd) {
+      const VT v = ac[j + 1] + (wA * rd) * (bu[j] - kx);
       dst[j] = ok1[j + 1] ? v : Z;
-    }
+    });
   };
 
   VT a0[N1], a1[N1], a2[N1];   // x' rows
@@ -1215,23 +1255,20 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     xp_row(row + 2, a2);
     bu_row(row + 1, u2);
     x3_row(row + 1, a0, a1, a2, u2, b2);
-    VT kx[RW];
-    float d0[RW], rd[RW];
-    k1_row<VT, RW, ND, EDGE>(L, row, c0w, b0, b1, b2, kx, d0, rd);
-#pragma unroll
-    for (int k = 0; k < RW; ++k) {
-      if (EDGE && c0w + k >= W) continue;
-      const VT z = b1[k + 1] + (wB * rd[k]) * (u1[k + 1] - kx[k]);
-      *(VT*)(pz + (i64)k * Bp + lb) = z;
-      if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);     // (r / s_b) . z; times s_b after the loop
-    }
+    k1_row<VT, RW, ND, EDGE>(cf, n, W, row, c0w, b0, b1, b2, [&](int k, VT kx, typename CF::T, typename CF::T rd) {
+      if (!EDGE || c0w + k < W) {
+        const VT z = b1[k + 1] + (wB * rd) * (u1[k + 1] - kx);
+        *(VT*)(pz + (i64)k * Bp + lb) = z;
+        if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);     // (r / s_b) . z; times s_b after the loop
+      }
+    });
     pz += (i64)W * Bp;
 #pragma unroll
     for (int j = 0; j < N2; ++j) { b0[j] = b1[j]; b1[j] = b2[j]; u1[j] = u2[j]; }
   }
 }
 
-template <typename VT, int ND, int RW, bool DOT>
+template <typename VT, int ND, int RW, bool DOT, bool SHARED>
 __global__ __launch_bounds__(256) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
@@ -1254,8 +1291,10 @@ __global__ __launch_bounds__(256) void fused_post_kernel(Level L, const double* 
   double s0 = 0.0, s1 = 0.0;
   if (active) {
     const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
-    if (edge) fused_post_body<VT, ND, RW, true, DOT>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
-    else fused_post_body<VT, ND, RW, false, DOT>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+    if (edge)
+      fused_post_body<VT, ND, RW, true, DOT, SHARED>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+    else
+      fused_post_body<VT, ND, RW, false, DOT, SHARED>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
   }
   if (DOT) {
     const double f0 = scale ? scale[lb] : 1.0;
@@ -1390,34 +1429,48 @@ inline int fused_mode() {
   return on ? (spl == 1 ? 1 : 2) : 0;
 }
 inline unsigned fused_lds() {
-  static const unsigned v = getenv("DIFFHE_FUSED_LDS") ? (unsigned)atoi(getenv("DIFFHE_FUSED_LDS")) : 40000u;
+  // dynamic LDS per block = a cap on the blocks resident per CU; the fused passes (118-125 VGPRs: 4 waves per SIMD
+  // anyway) run best without one (gpurun_out/r3w: 93.9 ms per step at 0, 94.4 at 40 000, 103.8 at 54 000)
+  static const unsigned v = getenv("DIFFHE_FUSED_LDS") ? (unsigned)atoi(getenv("DIFFHE_FUSED_LDS")) : 0u;
   return v;
 }
 
-void launch_fused_pre(const Level& L, const Level& C, const double* scale, const float* rhs, float* x2, float* crhs,
+// fused passes apply to: a batch-shared matrix with its fp32 copy, reciprocal diagonal and mask (strip2_ok), or a
+// per-sample matrix with the compact copies (fp32 diagonal + scaled fp16 off-diagonals) and the mask, no per-sample scale
+inline bool fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
+  if (strip2_ok(L, Bv, Bp)) return true;
+  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 1;
+  return per_sample && Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale;
+}
+
+void launch_fused_pre(const Level& L, const Level& C, int Bv, const double* scale, const float* rhs, float* x2, float* crhs,
                       double w0, double w1, int Bp, const StripGeom& g, int spl, hipStream_t st) {
   constexpr int CW = kRestrictCols;
-  diffhe::account(9.0 * (double)L.n * Bp);   // r read, x2 and the coarse rhs written
+  // r read, x2 and the coarse rhs written; per-sample matrices: + the compact coefficients (read by both stages)
+  diffhe::account((9.0 + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPRE(VT_, ND_)                                                                                               \
-  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,     \
+#define FPRE(VT_, ND_, SH_)                                                                                               \
+  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW, SH_>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,     \
                      (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
-  if (spl == 2) { if (L.nd == 3) FPRE(v2f, 3); else FPRE(v2f, 4); }
-  else { if (L.nd == 3) FPRE(float, 3); else FPRE(float, 4); }
+  if (Bv != 1) { if (L.nd == 3) FPRE(v2f, 3, false); else FPRE(v2f, 4, false); }
+  else if (spl == 2) { if (L.nd == 3) FPRE(v2f, 3, true); else FPRE(v2f, 4, true); }
+  else { if (L.nd == 3) FPRE(float, 3, true); else FPRE(float, 4, true); }
 #undef FPRE
 }
 
-void launch_fused_post(const Level& L, const Level& C, const double* scale, const float* xin, const float* rhs,
+void launch_fused_post(const Level& L, const Level& C, int Bv, const double* scale, const float* xin, const float* rhs,
                        const float* ec, float* z, double wA, double wB, double* part, int Bp, const StripGeom& g, int spl,
                        hipStream_t st) {
-  diffhe::account(13.0 * (double)L.n * Bp);  // x2, r, a quarter of e read; z written
+  // x2, r, a quarter of e read; z written (+ compact coefficients of a per-sample matrix)
+  diffhe::account((13.0 + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPOST(VT_, ND_, DOT_)                                                                                           \
-  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, z, \
+#define FPOST(VT_, ND_, DOT_, SH_)                                                                                           \
+  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, z, \
                      (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
-#define FPOSTD(VT_, ND_) do { if (part) FPOST(VT_, ND_, true); else FPOST(VT_, ND_, false); } while (0)
-  if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3); else FPOSTD(v2f, 4); }
-  else { if (L.nd == 3) FPOSTD(float, 3); else FPOSTD(float, 4); }
+#define FPOSTD(VT_, ND_, SH_) do { if (part) FPOST(VT_, ND_, true, SH_); else FPOST(VT_, ND_, false, SH_); } while (0)
+  if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
+  else if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
+  else { if (L.nd == 3) FPOSTD(float, 3, true); else FPOSTD(float, 4, true); }
 #undef FPOSTD
 #undef FPOST
 }
@@ -2155,10 +2208,10 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
     fused[l] = false;
-    if (sizeof(TV) == 4 && H.fuse && H.nu == 2 && strip2_ok(L, H.Bv, H.Bp)) {
+    if (sizeof(TV) == 4 && H.fuse && H.nu == 2 && fused_ok(L, H.Bv, H.Bp, H.scale)) {
       // both sweeps + residual + restriction in ONE pass (fused_pre_kernel); the way up is fused_post_kernel
       const Level& C = H.lev[l + 1];
-      const int spl = H.fuse;
+      const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
       if (L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use) {
         constexpr int CW = kRestrictCols;
         StripGeom g{true, 0, 0, 0};
@@ -2170,10 +2223,10 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
         g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
         gpost[l] = strip_geom(L, H.Bp, 4, spl);
-        if (strip2_tile_fits(L, H.Bp, 2 * g.TR + 4) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 3)) {
+        if (strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 5)) {
           if (l == 0) kp_begin(KP_FIRST2, st);
-          launch_fused_pre(L, C, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0], H.omega[1],
-                           H.Bp, g, spl, st);
+          launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
+                           H.omega[1], H.Bp, g, spl, st);
           if (l == 0) kp_end(KP_FIRST2, st);
           fused[l] = true;
           cur[l] = a;
@@ -2246,8 +2299,8 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     if (fused[l]) {   // prolongation + correction + both post-sweeps (+ the partials of rhs . z) in ONE pass
       const bool dot = (l == l0) && rz_part;
       if (l == 0) kp_begin(KP_PROLONG, st);
-      launch_fused_post(L, C, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
-                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.fuse, st);
+      launch_fused_post(L, C, H.Bv, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
+                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.Bv == 1 ? H.fuse : 2, st);
       if (l == 0) kp_end(KP_PROLONG, st);
       if (dot && rz_blocks) *rz_blocks = gpost[l].ncb * gpost[l].nrc;
       cur[l] = b2;
@@ -2666,6 +2719,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 }
 
 extern "C" int diffhe_lattice_blocks(int n, int Bp) { (void)n; (void)Bp; return kPartBlocks; }
+
+extern "C" int diffhe_lattice_fused_passes(void) { return fused_mode(); }
 
 extern "C" int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x,
                                     double* y, double* part, int Bp, void* stream) {

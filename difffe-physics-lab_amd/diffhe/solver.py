@@ -347,8 +347,8 @@ class _Engine:
             arr[i].dense_inv = dense[1].data_ptr() if dense is not None and i == nl - 1 else None
             arr[i].shift = shift[i].data_ptr() if shift is not None else None
             arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
-            arr[i].mask32 = lev.mask32().data_ptr() if arr[i].rdiag32 else None
             arr[i].offdiag16 = off16[i].data_ptr() if off16 is not None and off16[i] is not None else None
+            arr[i].mask32 = lev.mask32().data_ptr() if (arr[i].rdiag32 or arr[i].offdiag16) else None
             arr[i].offdiag_scale = oscale if arr[i].offdiag16 else 0.0
         return arr
 

@@ -314,6 +314,12 @@ int diffhe_lattice_kernel_profile(int id, double* total_ms, long long* launches)
  * `part`, diffhe_lattice_blocks(n, Bp) * Bp doubles) and one damped-Jacobi sweep
  * xout = xin + omega (rhs - A xin)/D  (xin NULL = 0). */
 int diffhe_lattice_blocks(int n, int Bp);
+/* 0: the fp32 V-cycle of a batch-shared matrix runs four single-stage strip passes per level; 1 / 2: the fused
+ * two-stage passes (pre-smoothing + residual + restriction; prolongation + post-smoothing) with that many samples per
+ * lane (environment DIFFHE_FUSED / DIFFHE_FUSED_SPL; flag bit 6 of diffhe_lattice_pcg_solve switches them off per call).
+ * With them, kernel-profile id 2 times the fused PRE pass (9 B per node and sample), id 4 the fused POST pass (13 B),
+ * ids 3 and 5 see no launches. */
+int diffhe_lattice_fused_passes(void);
 int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x, double* y,
                          double* part, int Bp, void* stream);
 int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,

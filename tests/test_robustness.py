@@ -322,6 +322,8 @@ def _partly_neumann(nx, ny):
     ("skewed lattice (4 diagonals)", _skewed(272, 232), "sample"),
     ("partly Neumann boundary (assembled scalar-kappa operator, shared)", _partly_neumann(240, 224), "scalar"),
     ("one per-element field shared by the batch", FEMesh.rectangle(288, 264), "field"),
+    ("one field PER SAMPLE (per-sample matrices: fused passes on compact per-lane coefficients)", FEMesh.rectangle(272, 240, bc_value=0.3), "fields"),
+    ("one field per sample, skewed lattice (4 diagonals)", _skewed(240, 216, seed=2), "fields"),
 ])
 def test_two_samples_per_lane_kernels_agree_with_the_one_sample_kernels_and_the_oracle(name, mesh, kind):
     """B = 128 puts the fp32 V-cycle of a batch-shared matrix on dia_strip2_kernel (packed fp32 arithmetic, 8 B per
@@ -333,6 +335,8 @@ def test_two_samples_per_lane_kernels_agree_with_the_one_sample_kernels_and_the_
         kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
     elif kind == "scalar":
         kappa = torch.tensor(1.37, dtype=T64)
+    elif kind == "fields":
+        kappa = torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))
     else:
         kappa = torch.exp(0.3 * torch.randn(m, generator=gen, dtype=T64))
     f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
@@ -346,13 +350,15 @@ def test_two_samples_per_lane_kernels_agree_with_the_one_sample_kernels_and_the_
             assert float((a - b).abs().max() / b.abs().max()) < 2e-11, name
     bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
     for b in (0, B - 1):
-        kb = float(kappa[b]) if kind == "sample" else kappa.numpy()
+        kb = float(kappa[b]) if kind == "sample" else (kappa[b].numpy() if kind == "fields" else kappa.numpy())
         uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kb, f[b].numpy(),
                                             lambda u_: 2 * u_, sparse=True, refine=1)
         assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U, name
         assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD, name
         if kind == "sample":
             assert abs(float(new[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum()), name
+        if kind == "fields":
+            assert rel_err(new[1][b].cpu().numpy(), dk) < RTOL_GRAD, name
 
 
 # ---- per-sample kappa fields: operator and coefficient-storage forms ----------------------------------------------------
