@@ -1437,10 +1437,11 @@ inline unsigned fused_lds() {
 
 // fused passes apply to: a batch-shared matrix with its fp32 copy, reciprocal diagonal and mask (strip2_ok), or a
 // per-sample matrix with the compact copies (fp32 diagonal + scaled fp16 off-diagonals) and the mask, no per-sample scale
-inline bool fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
-  if (strip2_ok(L, Bv, Bp)) return true;
-  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 1;
-  return per_sample && Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale;
+// returns a bit mask: 1 = the PRE pass may be fused, 2 = the POST pass
+inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
+  if (strip2_ok(L, Bv, Bp)) return 3;
+  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 3;
+  return (Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale) ? per_sample : 0;
 }
 
 void launch_fused_pre(const Level& L, const Level& C, int Bv, const double* scale, const float* rhs, float* x2, float* crhs,
@@ -2208,7 +2209,8 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
     fused[l] = false;
-    if (sizeof(TV) == 4 && H.fuse && H.nu == 2 && fused_ok(L, H.Bv, H.Bp, H.scale)) {
+    const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
+    if (fmask) {
       // both sweeps + residual + restriction in ONE pass (fused_pre_kernel); the way up is fused_post_kernel
       const Level& C = H.lev[l + 1];
       const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
@@ -2223,12 +2225,13 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
         g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
         gpost[l] = strip_geom(L, H.Bp, 4, spl);
-        if (strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 5)) {
+        const bool fits = strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 5);
+        fused[l] = fits && (fmask & 2);          // the way up: fused POST pass
+        if (fits && (fmask & 1)) {
           if (l == 0) kp_begin(KP_FIRST2, st);
           launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
                            H.omega[1], H.Bp, g, spl, st);
           if (l == 0) kp_end(KP_FIRST2, st);
-          fused[l] = true;
           cur[l] = a;
           rhs[l + 1] = (const TV*)H.rhs[l + 1];
           continue;
