@@ -1440,7 +1440,10 @@ inline unsigned fused_lds() {
 // returns a bit mask: 1 = the PRE pass may be fused, 2 = the POST pass
 inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
   if (strip2_ok(L, Bv, Bp)) return 3;
-  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 3;
+  // per-sample matrices: only the POST pass is fused by default -- the fused PRE pass needs three window rows of x1 AND
+  // per-lane coefficients for three stages (256 VGPRs, one wave per SIMD) and measured slower than its two single passes
+  // (1024^2 x 256 forward solve: 153.1 ms PRE only, 135.5 POST only, 147.9 both, 140.6 neither; gpurun_out/r3y)
+  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 2;
   return (Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale) ? per_sample : 0;
 }
 
