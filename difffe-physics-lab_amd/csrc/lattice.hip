@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
 }
 
 template <typename VT, int ND, int CW, bool SHARED>
-__global__ __launch_bounds__(256) void fused_pre_kernel(Level L, const double* __restrict__ scale,
+__global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_pre_kernel(Level L, const double* __restrict__ scale,
                                                          const float* __restrict__ rhs, float* __restrict__ x2out,
                                                          float* __restrict__ crhs, float w0, float w1, int cW,
                                                          const unsigned char* __restrict__ cbc, int Bp, int ncb, int TR) {
@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
 }
 
 template <typename VT, int ND, int RW, bool DOT, bool SHARED>
-__global__ __launch_bounds__(256) void fused_post_kernel(Level L, const double* __restrict__ scale,
+__global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
                                                           float wB, int cW, double* __restrict__ part, int Bp, int ncb,

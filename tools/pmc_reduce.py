@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
+KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "fused_pre_kernel", "fused_post_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
         "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel",
         "cg_spmv_kernel", "ell_jacobi_kernel", "ell_galerkin_kernel", "ell_residual_out_kernel", "agg_restrict_kernel",
         "sa_prolong_add_kernel", "amg_update_kernel", "assemble_rows_kernel", "lattice_grad_kappa_kernel",
@@ -23,9 +23,15 @@ KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "dia
 
 
 def short(name):
+    """Kernel symbol without the `void`, the anonymous namespace and the argument list (template arguments may contain
+    parentheses themselves: `float __vector(2)`)."""
     name = name.replace("(anonymous namespace)::", "")
-    m = re.match(r"(void )?([^(]+)", name)
-    return (m.group(2) if m else name).strip()
+    if name.startswith("void "):
+        name = name[5:]
+    cut = name.find(">(")
+    if cut >= 0:
+        return name[:cut + 1].strip()
+    return name.split("(")[0].strip()
 
 
 def collect(d, counter):

@@ -18,6 +18,8 @@ RULES = [
     ("dia_strip_kernel<double, double, double, 0, 4", "fused CG step, z/p fp64", 4.0),
     ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step with the x update (isolated launches of bench.py only)", 4.5),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
+    ("fused_pre_kernel", "fused PRE pass: two sweeps from 0 + residual + restriction (fp32, two samples per lane)", 1.125),
+    ("fused_post_kernel", "fused POST pass: prolongation + correction + two sweeps (fp32, two samples per lane)", 1.625),
     ("dia_strip2_kernel<2, 0, 3, true", "first two Jacobi sweeps from 0 (fp32, two samples per lane)", 1.0),
     ("dia_strip2_kernel<1, 3", "residual + restriction, residual never stored (fp32, two samples per lane)", 1.125),
     ("dia_strip2_kernel<2, 1", "prolong + correct + Jacobi sweep (fp32, two samples per lane)", 1.625),
@@ -54,7 +56,8 @@ def main(path):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             total += d
-            per[name.split("(")[0]].append(d)
+            cut = name.find(">(")
+            per[name[:cut + 1] if cut >= 0 else name.split("(")[0]].append(d)
     print("| kernel | launches (fine level) | avg ms | algorithmic GB/s | frac of 8 TB/s | share of GPU time |")
     print("|---|---|---|---|---|---|")
     seen = 0
