@@ -1181,25 +1181,20 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   const rsrc_t rc = make_rsrc(ec + (i64)cr0 * cW * Bp);
   const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp, rowCB = 4u * (unsigned)cW * (unsigned)Bp;
 
-  // x' = x + mask (P e) on grid row R, in two steps so that the loop can issue the loads of the NEXT row before it
-  // computes on the current one (memory-level parallelism: the pass is latency-bound, not traffic-bound)
-  auto xp_load = [&](int R, VT* rawx, VT* ce, VT* ce2) {
-    if (EDGE && (R < 0 || R >= nyp)) return;
-    const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
-    const unsigned sc = (unsigned)((R >> 1) - cr0) * rowCB;
-#pragma unroll
-    for (int j = 0; j < NCE; ++j) {
-      ce[j] = VLane<VT>::ld(rc, offc[j], sc);
-      ce2[j] = (R & 1) ? VLane<VT>::ld(rc, offc[j], sc + rowCB) : Z;
-    }
-#pragma unroll
-    for (int j = 0; j < N1; ++j) rawx[j] = VLane<VT>::ld(rx, off1[j], sx);
-  };
-  auto xp_form = [&](int R, const VT* rawx, const VT* ce, const VT* ce2, VT* dst) {
+  // x' = x + mask (P e) on grid row R
+  auto xp_row = [&](int R, VT* dst) {
     if (EDGE && (R < 0 || R >= nyp)) {
 #pragma unroll
       for (int j = 0; j < N1; ++j) dst[j] = Z;
       return;
+    }
+    const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
+    const unsigned sc = (unsigned)((R >> 1) - cr0) * rowCB;
+    VT ce[NCE], ce2[NCE];
+#pragma unroll
+    for (int j = 0; j < NCE; ++j) {
+      ce[j] = VLane<VT>::ld(rc, offc[j], sc);
+      ce2[j] = (R & 1) ? VLane<VT>::ld(rc, offc[j], sc + rowCB) : Z;
     }
     const i64 rb = (i64)R * W + (c0w - 2);
 #pragma unroll
@@ -1211,31 +1206,20 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
         corr = (R & 1) ? 0.5f * (ce[(j + 1) / 2] + ce2[(j - 1) / 2]) : 0.5f * (ce[(j - 1) / 2] + ce[(j + 1) / 2]);
       i64 i = rb + j;
       if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-      const VT v = rawx[j] + L.mk32[i] * corr;
+      const VT v = VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
       dst[j] = ok1[j] ? v : Z;
     }
   };
-  auto xp_row = [&](int R, VT* dst) {
-    VT rawx[N1], ce[NCE], ce2[NCE];
-    xp_load(R, rawx, ce, ce2);
-    xp_form(R, rawx, ce, ce2, dst);
-  };
-  // bu = r / s_b on grid row R at the N2 columns c0w - 1 + j (load / form, as above)
-  auto bu_load = [&](int R, VT* raw) {
-    if (EDGE && (R < 0 || R >= nyp)) return;
+  // bu = r / s_b on grid row R at the N2 columns c0w - 1 + j
+  auto bu_row = [&](int R, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N2; ++j) dst[j] = Z;
+      return;
+    }
     const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
 #pragma unroll
-    for (int j = 0; j < N2; ++j) raw[j] = VLane<VT>::ld(rr, off1[j + 1], sx);
-  };
-  auto bu_form = [&](int R, const VT* raw, VT* dst) {
-    const bool out = EDGE && (R < 0 || R >= nyp);
-#pragma unroll
-    for (int j = 0; j < N2; ++j) dst[j] = (!out && ok1[j + 1]) ? raw[j] * ib : Z;
-  };
-  auto bu_row = [&](int R, VT* dst) {
-    VT raw[N2];
-    bu_load(R, raw);
-    bu_form(R, raw, dst);
+    for (int j = 0; j < N2; ++j) dst[j] = ok1[j + 1] ? VLane<VT>::ld(rr, off1[j + 1], sx) * ib : Z;
   };
   // x3 on grid row R (window N2) from x' rows R - 1, R, R + 1 and bu row R
   auto x3_row = [&](int R, const VT* am, const VT* ac, const VT* ap, const VT* bu, VT* dst) {
@@ -1264,19 +1248,12 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   bu_row(r0, u1);
   x3_row(r0, a0, a1, a2, u1, b1);
   float* __restrict__ pz = zout + ((i64)r0 * W + c0w) * Bp;
-  VT sx_[N1], sce[NCE], sce2[NCE], sr_[N2];    // staging: raw x / coarse values of row + 2 and raw rhs of row + 1
-  xp_load(r0 + 2, sx_, sce, sce2);
-  bu_load(r0 + 1, sr_);
 
   for (int row = r0; row < r1; ++row) {
 #pragma unroll
     for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
-    xp_form(row + 2, sx_, sce, sce2, a2);
-    bu_form(row + 1, sr_, u2);
-    if (row + 1 < r1) {                         // next iteration's rows: in flight during this iteration's arithmetic
-      xp_load(row + 3, sx_, sce, sce2);
-      bu_load(row + 2, sr_);
-    }
+    xp_row(row + 2, a2);
+    bu_row(row + 1, u2);
     x3_row(row + 1, a0, a1, a2, u2, b2);
     k1_row<VT, RW, ND, EDGE>(cf, n, W, row, c0w, b0, b1, b2, [&](int k, VT kx, typename CF::T, typename CF::T rd) {
       if (!EDGE || c0w + k < W) {
@@ -1292,7 +1269,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
 }
 
 template <typename VT, int ND, int RW, bool DOT, bool SHARED>
-__global__ __launch_bounds__(256, SHARED ? 3 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
+__global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
                                                           float wB, int cW, double* __restrict__ part, int Bp, int ncb,
