@@ -212,11 +212,16 @@ def main():
     if rank == 0:
         L.diffhe_lattice_pcg_profile(1, None, None)
     L.diffhe_traffic_account(1, None, None)
+    seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, u = step()
+        marks.append(time.perf_counter())           # host clock only: every solve already waits for its own status
     torch.cuda.synchronize(dev)
     own_elapsed = time.perf_counter() - t0          # this rank's own time, before it waits for the others
+    seg1 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    step_ms = [1e3 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]
     sync_all()
     elapsed = time.perf_counter() - t0
     L.diffhe_traffic_account(1, ctypes.byref(acc_bytes), ctypes.byref(acc_launches))
@@ -249,10 +254,16 @@ def main():
         for _ in range(reps or args.variant_reps):
             if world > 1:
                 dist.barrier()
+            sg = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
             tv = time.perf_counter()
             fn()
             torch.cuda.synchronize(dev)
             ts.append(time.perf_counter() - tv)
+            if os.environ.get("DIFFHE_BENCH_DEBUG"):
+                st_ = torch.cuda.memory_stats(dev)
+                print(f"[timed] {1e3 * ts[-1]:.2f} ms, device allocations {st_.get('segment.all.allocated', 0) - sg}, "
+                      f"reserved {st_.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB, "
+                      f"retries {st_.get('num_alloc_retries', 0)}", file=sys.stderr, flush=True)
         return statistics.median(ts), ts
 
     variants = {}
@@ -421,6 +432,9 @@ def main():
                              "max_relres_adj": max(r_[3] for r_ in it) if it else None,
                              "not_converged": max(r_[4] for r_ in it) if it else None},
             "per_rank_step_ms": _spread(rank_ms),
+            "timed_steps_ms": {**_spread(step_ms), "all": [round(x, 2) for x in step_ms],
+                               "device_allocations_in_timed_region": int(seg1 - seg0),
+                               "note": "rank 0's host clock after each timed step (value = steps / their SUM, nothing dropped)"},
             "headline_note": (f"{round(value, 1)} solves/s = factored scalar-kappa operator, p and V-cycle vectors stored "
                               f"fp32; ALL vectors stored fp64: {v64} solves/s/GPU; per-element kappa field per sample "
                               f"(general case, one matrix per sample): {vel} solves/s/GPU") if single and variants else None,
@@ -687,8 +701,8 @@ KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, f
                        "dia_strip_kernel<float, float, double, 2, 0, 3, true, false, 4, 1>"]
 
 
-KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2>",
-                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true>", KERNEL_SYMBOLS_FP32[5]]
+KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true>",
+                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true>", KERNEL_SYMBOLS_FP32[5]]
 
 
 def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, prof_n, kprof=()):
