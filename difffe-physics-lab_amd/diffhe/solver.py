@@ -919,19 +919,105 @@ def _fe_solve_backward_fake(gbar, token, need_k, need_f, need_load, kappa_like, 
 def _fe_setup_context(ctx, inputs, output):
     kappa, f, load, _, _, node_major = inputs
     # node-major: u may BE the solver's saved iterate -- saving it lets autograd refuse a backward after an in-place edit
-    ctx.save_for_backward(output[1], kappa, f, load, *((output[0],) if node_major else ()))
-    if not isinstance(output[1], torch._subclasses.FakeTensor):
-        ctx.state_guard = _StateGuard(int(output[1]))       # frees the adjoint state together with the graph
+    real = not isinstance(output[1], torch._subclasses.FakeTensor)
+    # A sentinel among the saved tensors: autograd drops its saved tensors at the end of a backward pass that does not
+    # retain the graph, the sentinel dies with them and takes the adjoint state (per-sample operators, iterates: tens of
+    # GB at the bench size) along -- BEFORE the caller lets go of u / the loss.  A state that lived until then overlaps
+    # the next step's forward solve and the caching allocator has to find a second set of blocks for it: measured as
+    # new device allocations (hipMalloc, 70-700 ms each) in otherwise steady 93 ms steps.
+    sentinel = (torch.empty(0),) if real else ()
+    ctx.save_for_backward(output[1], kappa, f, load, *((output[0],) if node_major else ()), *sentinel)
+    ctx.handle, ctx.node_major = inputs[3], bool(node_major)
+    if real:
+        weakref.finalize(sentinel[0], _STATES.pop, int(output[1]), None)
+        ctx.state_guard = _StateGuard(int(output[1]))       # and in any case together with the graph
+
+
+def _element_forms(plan: SolvePlan):
+    """Unit-kappa element stiffness and load matrices (m, npe, npe) and the (m, npe) connectivity, as torch tensors
+    built from the plan's coordinates -- the differentiable restatement of reference solver.py:86-96 (1D) and :125-145
+    (2D P1) used by the second-order path only."""
+    cached = plan.__dict__.get("_element_forms")
+    if cached is not None:
+        return cached
+    if plan.npe != plan.dim + 1:
+        raise NotImplementedError("diffhe: second-order derivatives are implemented for P1 elements only")
+    el = plan.elems.long().t().contiguous()                          # (m, npe)
+    X = plan.coords.to(torch.float64)                                # (dim, n)
+    if plan.dim == 1:
+        h = (X[0][el[:, 1]] - X[0][el[:, 0]]).abs()
+        k0 = torch.tensor([[1.0, -1.0], [-1.0, 1.0]], dtype=torch.float64, device=h.device)[None] / h[:, None, None]
+        m0 = torch.eye(2, dtype=torch.float64, device=h.device)[None] * (0.5 * h)[:, None, None]
+    else:
+        x, y = X[0][el], X[1][el]                                    # (m, 3)
+        b = torch.stack([y[:, 1] - y[:, 2], y[:, 2] - y[:, 0], y[:, 0] - y[:, 1]], 1)
+        c = torch.stack([x[:, 2] - x[:, 1], x[:, 0] - x[:, 2], x[:, 1] - x[:, 0]], 1)
+        area = 0.5 * ((x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])).abs()
+        k0 = (b[:, :, None] * b[:, None, :] + c[:, :, None] * c[:, None, :]) / (4.0 * area)[:, None, None]
+        m0 = (area / 9.0)[:, None, None].expand(-1, 3, 3).contiguous()
+    plan.__dict__["_element_forms"] = (el, k0, m0)
+    return el, k0, m0
+
+
+def _second_order_backward(ctx, grad_u):
+    """The adjoint written with differentiable pieces, for backward(create_graph=True) / Hessian-vector products:
+
+        lambda = A(kappa)^-1 gbar          a solve of the SAME solver class on the mesh with homogeneous Dirichlet data
+                                           (gbar enters as `load`: rows of Dirichlet nodes dropped), itself differentiable;
+        u      = the forward solve again   (recorded this time: the first one's graph ends at the custom op);
+        dL/dkappa_e = - lambda_e^T k0_e u_e,   dL/df = M^T lambda,   dL/dload = lambda      plain torch gathers / sums.
+
+    Costs two HIP solves per first-order gradient instead of one, and element-local torch temporaries of (B, m, npe):
+    meant for the sizes Hessian-vector products are taken at, not for the first-order hot path (which never comes here).
+    Each further derivative of the result runs the explicit adjoint of those two solves (or, with create_graph again,
+    this function recursively)."""
+    solver = _SOLVERS.get(ctx.handle)
+    if solver is None:
+        raise RuntimeError("diffhe: the solver of this solve is gone; second-order backward needs it alive")
+    _token, kappa, f, load = ctx.saved_tensors[:4]
+    node_major = ctx.node_major
+    need_k, need_f, need_load = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    plan = solver._plan()
+    el, k0, m0 = _element_forms(plan)
+    m, n = plan.m, plan.n
+    twin = solver._adjoint_twin()
+    _SOLVERS[id(twin)] = twin
+    g = grad_u.to(torch.float64)
+    lam, _ = torch.ops.diffhe.fe_solve(kappa, torch.zeros_like(g), g, id(twin), True, node_major)
+    u, _ = torch.ops.diffhe.fe_solve(kappa, f, load, ctx.handle, True, node_major)
+    # (B, n) views for the element-local maps
+    lam_b = (lam.t() if node_major else lam).reshape(-1, n)
+    u_b = (u.t() if node_major else u).reshape(-1, n)
+    B = lam_b.shape[0]
+    gk = gf = gl = None
+    if need_k:
+        B_f = B if (f.dim() == 2) else None
+        kappa_em = bool(node_major and kappa.dim() == 2 and tuple(kappa.shape) == (m, B))
+        mode, _ = (K_SAMPLE_ELEM, B) if kappa_em else _kappa_mode(kappa, m, B_f)
+        s_be = -torch.einsum("bep,epq,beq->be", lam_b[:, el], k0, u_b[:, el])      # (B, m)
+        if mode == K_SCALAR:
+            gk = s_be.sum().reshape(kappa.shape)
+        elif mode == K_SAMPLE:
+            gk = s_be.sum(1).reshape(kappa.shape)
+        elif mode == K_ELEM:
+            gk = s_be.sum(0).reshape(kappa.shape)
+        else:
+            gk = (s_be.t() if kappa_em else s_be).reshape(kappa.shape)
+    if need_f:
+        y = torch.einsum("epq,beq->bep", m0, lam_b[:, el])                          # M^T lambda, M symmetric per element
+        gf_b = torch.zeros_like(lam_b).index_add_(1, el.reshape(-1), y.reshape(B, -1))
+        gf = (gf_b.t() if node_major else gf_b).reshape(f.shape) if f.dim() == lam.dim() else gf_b.sum(0).reshape(f.shape)
+    if need_load:
+        gl = lam.reshape(load.shape) if load.dim() == lam.dim() else lam_b.sum(0).reshape(load.shape)
+    return gk, gf, gl, None, None, None
 
 
 def _fe_backward(ctx, grad_u, _grad_token):
     if torch.is_grad_enabled():
         # backward(create_graph=True) / autograd.grad(..., create_graph=True): the caller wants a gradient it can
-        # differentiate again.  The explicit adjoint below is not recorded by autograd, so what it returns would carry
-        # no graph and a Hessian-vector product taken through it would silently be wrong (zero) -- refuse instead.
-        raise RuntimeError("diffhe: second-order derivatives through DifferentiableFESolver are not implemented "
-                           "(the adjoint solve is explicit and not itself differentiable): backward/grad was called with "
-                           "create_graph=True.  Use first-order gradients, or finite differences of them.")
+        # differentiate again.  The explicit adjoint below is not recorded by autograd (what it returns would carry no
+        # graph, a Hessian-vector product through it would silently be zero): take the differentiable restatement.
+        return _second_order_backward(ctx, grad_u)
     token, kappa, f, load = ctx.saved_tensors[:4]
     need_k, need_f, need_load = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
     gk, gf, gl = torch.ops.diffhe.fe_solve_backward(grad_u, token, need_k, need_f, need_load, kappa, f, load)
@@ -1055,6 +1141,24 @@ class DifferentiableFESolver(nn.Module):
 
     def _plan(self) -> SolvePlan:
         return get_plan(self.mesh, _resolve_device(self._device))
+
+    def _adjoint_twin(self) -> "DifferentiableFESolver":
+        """This solver on the same mesh with HOMOGENEOUS Dirichlet data: u = A^-1 load, the adjoint solve as a
+        differentiable call (second-order path).  Built once per solver; options are re-read at every use."""
+        twin = self.__dict__.get("_twin")
+        if twin is None:
+            mesh0 = self.mesh.__dict__.get("_diffhe_zero_twin")
+            if mesh0 is None:
+                mesh0 = FEMesh(nodes=self.mesh.nodes, elements=self.mesh.elements,
+                               dirichlet_nodes={k: 0.0 for k in self.mesh.dirichlet_nodes})
+                self.mesh.__dict__["_diffhe_zero_twin"] = mesh0
+            twin = DifferentiableFESolver(mesh0, self._kappa, device=self._device)
+            self.__dict__["_twin"] = twin
+        for name in ("tol", "_tol_user", "max_iter", "check_every", "assembly", "method", "chain", "warm_start",
+                     "reaction", "operator", "_mg_user"):
+            setattr(twin, name, getattr(self, name))
+        twin.mg, twin.amg, twin.warm_start = dict(self.mg), dict(self.amg), False
+        return twin
 
     def forward(self, f: torch.Tensor, load: Optional[torch.Tensor] = None, layout: str = "sample") -> torch.Tensor:
         """Solve for nodal u.  f: (n,), (n,1) or (B,n); returns float64 (n,) or (B,n)

@@ -198,22 +198,110 @@ def test_forward_and_backward_of_two_solves_on_one_mesh_overlap_safely():
 
 
 # ---- second-order derivatives ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mesh", [FEMesh.line(40), FEMesh.rectangle(12, 10), FEMesh.rectangle(72, 64)])
-def test_double_backward_raises_instead_of_returning_a_gradient_without_graph(mesh):
-    """The reference is differentiable to any order (autograd through torch.linalg.solve, solver.py:174).  The explicit
-    adjoint here is first order: asking for a differentiable gradient must FAIL LOUDLY, not hand back a tensor with no
-    graph (whose 'Hessian-vector product' would silently be zero)."""
+def _dense_torch_solve(mesh, kappa_e, f):
+    """The reference's formulation in differentiable dense torch on the CPU (assembly solver.py:86-96 / :125-145, row
+    replacement for Dirichlet nodes :157-172, torch.linalg.solve :174): any-order autograd, the yardstick for Hessians."""
+    X, el = mesh.nodes.to(T64).reshape(mesh.n_nodes, -1), mesh.elements.long()
+    n, m = mesh.n_nodes, el.shape[0]
+    if X.shape[1] == 1:
+        h = (X[el[:, 1], 0] - X[el[:, 0], 0]).abs()
+        k0 = torch.tensor([[1.0, -1.0], [-1.0, 1.0]], dtype=T64)[None] / h[:, None, None]
+        m0 = torch.eye(2, dtype=T64)[None] * (0.5 * h)[:, None, None]
+    else:
+        x, y = X[el, 0], X[el, 1]
+        b = torch.stack([y[:, 1] - y[:, 2], y[:, 2] - y[:, 0], y[:, 0] - y[:, 1]], 1)
+        c = torch.stack([x[:, 2] - x[:, 1], x[:, 0] - x[:, 2], x[:, 1] - x[:, 0]], 1)
+        area = 0.5 * ((x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])).abs()
+        k0 = (b[:, :, None] * b[:, None, :] + c[:, :, None] * c[:, None, :]) / (4 * area)[:, None, None]
+        m0 = (area / 9)[:, None, None].expand(-1, 3, 3)
+    npe = el.shape[1]
+    rows = el[:, :, None].expand(m, npe, npe).reshape(-1)
+    cols = el[:, None, :].expand(m, npe, npe).reshape(-1)
+    K = torch.zeros(n * n, dtype=T64).index_add(0, rows * n + cols, (kappa_e[:, None, None] * k0).reshape(-1)).reshape(n, n)
+    F = torch.zeros(n, dtype=T64).index_add(0, el.reshape(-1), torch.einsum("epq,eq->ep", m0, f[el]).reshape(-1))
+    bc = torch.tensor(sorted(mesh.dirichlet_nodes), dtype=torch.long)
+    keep = torch.ones(n, dtype=T64); keep[bc] = 0
+    eye_bc = torch.zeros(n, n, dtype=T64); eye_bc[bc, bc] = 1
+    vals = torch.zeros(n, dtype=T64); vals[bc] = torch.tensor([mesh.dirichlet_nodes[int(i)] for i in bc], dtype=T64)
+    return torch.linalg.solve(K * keep[:, None] + eye_bc, F * keep + vals)
+
+
+@pytest.mark.parametrize("name,mesh", [("chain", FEMesh.line(40, bc_right=0.3)), ("lattice", FEMesh.rectangle(12, 10, bc_value=0.2)),
+                                       ("general", _unstructured(10, 9, seed=11))])
+def test_hessian_vector_products_match_dense_autograd(name, mesh):
+    """backward(create_graph=True): the reference is differentiable to any order (autograd through torch.linalg.solve,
+    solver.py:174); the second-order path here re-states the adjoint with differentiable solves.  d/dkappa and d/df of
+    <dL/dkappa, v> + <dL/df, w> against double backward through the dense formulation, per-element kappa."""
+    g = torch.Generator().manual_seed(5)
+    m, n = mesh.n_elements, mesh.n_nodes
+    k0 = torch.rand(m, generator=g, dtype=T64) + 0.5
+    f0 = torch.rand(n, generator=g, dtype=T64) + 0.5
+    v, w = torch.randn(m, generator=g, dtype=T64), torch.randn(n, generator=g, dtype=T64)
+
+    def second(solve, dev):
+        kap, f = k0.clone().to(dev).requires_grad_(True), f0.clone().to(dev).requires_grad_(True)
+        u = solve(kap, f)
+        L = (u ** 3).sum()                                   # not quadratic: d2L/du2 depends on u
+        gk, gf = torch.autograd.grad(L, (kap, f), create_graph=True)
+        assert gk.requires_grad and gf.requires_grad
+        hk, hf = torch.autograd.grad((gk * v.to(dev)).sum() + (gf * w.to(dev)).sum(), (kap, f))
+        return [t.detach().cpu() for t in (gk, gf, hk, hf)]
+
+    ref = second(lambda kap, f: _dense_torch_solve(mesh, kap, f), "cpu")
+    ours = second(lambda kap, f: DifferentiableFESolver(mesh, kap, device=DEV, tol=1e-14)(f), DEV)
+    for tag, a, b in zip(("dL/dkappa", "dL/df", "H.kappa", "H.f"), ours, ref):
+        assert rel_err(a.numpy(), b.numpy()) < 1e-9, (name, tag, rel_err(a.numpy(), b.numpy()))
+
+
+def test_hessian_vector_product_of_a_batch_with_scalar_kappa_and_node_layout():
+    """Per-sample scalar kappa (factored operator), (n, B) layout, a `load` term: second derivatives against central
+    differences of the FIRST-order (explicit-adjoint) gradient."""
+    mesh, B = FEMesh.rectangle(24, 20, bc_value=0.1), 64
+    g = torch.Generator().manual_seed(9)
+    k0 = (torch.rand(B, generator=g, dtype=T64) + 0.5).to(DEV)
+    f = torch.ones(mesh.n_nodes, B, dtype=T64, device=DEV)
+    load = (0.01 * torch.rand(mesh.n_nodes, B, generator=g, dtype=T64)).to(DEV)
+    v = torch.randn(B, generator=g, dtype=T64).to(DEV)
+
+    def grad(kv, create_graph=False):
+        kap = kv.clone().requires_grad_(True)
+        u = DifferentiableFESolver(mesh, kap, device=DEV, tol=1e-14)(f, load=load, layout="node")
+        gk, = torch.autograd.grad((u ** 3).sum(), kap, create_graph=create_graph)
+        return kap, gk
+
+    kap, gk = grad(k0, create_graph=True)
+    hv, = torch.autograd.grad((gk * v).sum(), kap)
+    _, g_first = grad(k0)
+    assert rel_err(gk.detach().cpu().numpy(), g_first.cpu().numpy()) < 1e-10
+    eps = 1e-5
+    fd = (grad(k0 + eps * v)[1] - grad(k0 - eps * v)[1]) / (2 * eps)      # H v for this per-sample (diagonal) Hessian
+    assert rel_err(hv.cpu().numpy(), fd.cpu().numpy()) < 1e-7
+
+
+def test_first_order_gradients_on_a_retained_graph_repeat_exactly():
+    mesh = FEMesh.rectangle(72, 64)
     kappa = torch.tensor(1.4, dtype=T64, device=DEV, requires_grad=True)
     f = torch.ones(mesh.n_nodes, dtype=T64, device=DEV)
-    u = DifferentiableFESolver(mesh, kappa, device=DEV)(f)
-    with pytest.raises(RuntimeError, match="second-order derivatives"):
-        torch.autograd.grad((u ** 2).sum(), kappa, create_graph=True)
-    # first order keeps working, repeatedly, on a retained graph
     u = DifferentiableFESolver(mesh, kappa, device=DEV)(f)
     L = (u ** 2).sum()
     g1, = torch.autograd.grad(L, kappa, retain_graph=True)
     g2, = torch.autograd.grad(L, kappa)
     assert torch.equal(g1, g2) and abs(float(g1) + 2 * float(L) / 1.4) < 1e-10 * abs(float(g1))
+    with pytest.raises(RuntimeError):                        # graph (and the adjoint state) released by the second call
+        torch.autograd.grad(L, kappa)
+
+
+def test_adjoint_state_is_released_with_the_backward_pass_not_with_the_outputs():
+    """The saved operators / iterates go when autograd drops its saved tensors, while u and the loss are still held."""
+    from diffhe import solver as S
+    mesh = FEMesh.rectangle(64, 64)
+    kappa = (torch.rand(64, mesh.n_elements, dtype=T64, device=DEV) + 0.5).requires_grad_(True)
+    u = DifferentiableFESolver(mesh, kappa, device=DEV)(torch.ones(64, mesh.n_nodes, dtype=T64, device=DEV))
+    L = (u ** 2).sum()
+    n0 = len(S._STATES)
+    assert n0 >= 1
+    L.backward()
+    assert len(S._STATES) == n0 - 1 and u.grad_fn is not None
 
 
 # ---- node-major entry -------------------------------------------------------------------------------------------------
