@@ -13,6 +13,7 @@
 // optional per-sample scale s_b on the free rows, K_b = s_b * K_1 -- the exact form of the
 // assembled operator when kappa is one scalar per sample (solver.py:88,139: k_e = kappa * k0_e).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -1438,6 +1439,18 @@ inline unsigned fused_lds() {
 // fused passes apply to: a batch-shared matrix with its fp32 copy, reciprocal diagonal and mask (strip2_ok), or a
 // per-sample matrix with the compact copies (fp32 diagonal + scaled fp16 off-diagonals) and the mask, no per-sample scale
 // returns a bit mask: 1 = the PRE pass may be fused, 2 = the POST pass
+// development knob: "a:b:c" = one integer per multigrid level (0 / missing = keep the default)
+inline int env_level_int(const char* name, int level) {
+  const char* e = getenv(name);
+  if (!e) return 0;
+  for (int l = 0; l < level; ++l) {
+    e = strchr(e, ':');
+    if (!e) return 0;
+    ++e;
+  }
+  return atoi(e);
+}
+
 inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
   if (strip2_ok(L, Bv, Bp)) return 3;
   // per-sample matrices: only the POST pass is fused by default -- the fused PRE pass needs three window rows of x1 AND
@@ -2226,8 +2239,15 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
         if (nrc < 1) nrc = 1;
         g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+        if (const int tr = env_level_int("DIFFHE_FUSED_TR_PRE", l)) g.TR = tr;
         g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
         gpost[l] = strip_geom(L, H.Bp, 4, spl);
+        if (const int tr = env_level_int("DIFFHE_FUSED_TR_POST", l)) {
+          if (gpost[l].ncb * ((L.ny + 1 + tr - 1) / tr) <= kPartBlocks) {
+            gpost[l].TR = tr;
+            gpost[l].nrc = (L.ny + 1 + tr - 1) / tr;
+          }
+        }
         const bool fits = strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 5);
         fused[l] = fits && (fmask & 2);          // the way up: fused POST pass
         if (fits && (fmask & 1)) {
