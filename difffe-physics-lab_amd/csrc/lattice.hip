@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_pre_kernel(Level L,
 
 // ---- POST: prolongation + correction + both post-smoothing sweeps (+ the partials of rhs . z) ------------------------
 // The wave owns the RW columns c0w .. c0w + RW - 1 (c0w a multiple of RW, even); rows r0 .. r1 - 1.
-template <typename VT, int ND, int RW, bool EDGE, bool DOT, bool SHARED>
+template <typename VT, int ND, int RW, bool EDGE, bool DOT, bool SHARED, bool XZ>
 __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const float* __restrict__ xin,
                                                 const float* __restrict__ rhs, const float* __restrict__ ec,
                                                 float* __restrict__ zout, float wA, float wB, int cW, int Bp, unsigned lb,
@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     offc[j] = 4u * ((unsigned)cj * (unsigned)Bp + lb);
   }
   const i64 tile0 = ((i64)(r0 - 2) * W + (c0w - 4)) * Bp;
-  const rsrc_t rx = make_rsrc(xin + tile0);
+  const rsrc_t rx = make_rsrc(XZ ? rhs + tile0 : xin + tile0);   // XZ: x = 0, never loaded
   const rsrc_t rr = make_rsrc(rhs + tile0);
   const int cr0 = (r0 - 2 > 0 ? r0 - 2 : 0) >> 1;
   const rsrc_t rc = make_rsrc(ec + (i64)cr0 * cW * Bp);
@@ -1207,7 +1207,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
         corr = (R & 1) ? 0.5f * (ce[(j + 1) / 2] + ce2[(j - 1) / 2]) : 0.5f * (ce[(j - 1) / 2] + ce[(j + 1) / 2]);
       i64 i = rb + j;
       if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-      const VT v = VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
+      const VT v = XZ ? L.mk32[i] * corr : VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
       dst[j] = ok1[j] ? v : Z;
     }
   };
@@ -1269,7 +1269,9 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   }
 }
 
-template <typename VT, int ND, int RW, bool DOT, bool SHARED>
+// XZ: the operand is P e alone (x = 0 is not read): two sweeps from a prolonged initial guess, the first stage of a
+// full-multigrid level (vcycle with `guess`)
+template <typename VT, int ND, int RW, bool DOT, bool SHARED, bool XZ = false>
 __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
@@ -1293,9 +1295,9 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L
   if (active) {
     const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
     if (edge)
-      fused_post_body<VT, ND, RW, true, DOT, SHARED>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+      fused_post_body<VT, ND, RW, true, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
     else
-      fused_post_body<VT, ND, RW, false, DOT, SHARED>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+      fused_post_body<VT, ND, RW, false, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
   }
   if (DOT) {
     const double f0 = scale ? scale[lb] : 1.0;
@@ -1326,7 +1328,9 @@ struct StripGeom {
 inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols, int spl = 1) {
   StripGeom g{false, 0, 0, 0};
   // small levels: one wave marching down a strip is latency-bound; the simple kernels win below ~200^2
-  if (Bp < kWave || L.W < 192 || L.ny + 1 < 64) return g;
+  // 128: the 129^2 level of a 1024^2 hierarchy takes the strip / fused kernels too (-0.7 ms per step; 64: slower again)
+  static const int minw = getenv("DIFFHE_STRIP_MINW") ? atoi(getenv("DIFFHE_STRIP_MINW")) : 128;
+  if (Bp < kWave || L.W < minw || L.ny + 1 < 64) return g;
   g.use = true;
   g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
   const int gy = Bp / (kWave * spl);   // spl = samples per lane (2: dia_strip2_kernel)
@@ -1478,13 +1482,18 @@ void launch_fused_pre(const Level& L, const Level& C, int Bv, const double* scal
 void launch_fused_post(const Level& L, const Level& C, int Bv, const double* scale, const float* xin, const float* rhs,
                        const float* ec, float* z, double wA, double wB, double* part, int Bp, const StripGeom& g, int spl,
                        hipStream_t st) {
-  // x2, r, a quarter of e read; z written (+ compact coefficients of a per-sample matrix)
-  diffhe::account((13.0 + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
+  // x2, r, a quarter of e read; z written (+ compact coefficients of a per-sample matrix); xin == NULL: x2 = 0, not read
+  diffhe::account(((xin ? 13.0 : 9.0) + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPOST(VT_, ND_, DOT_, SH_)                                                                                           \
-  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, z, \
-                     (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
-#define FPOSTD(VT_, ND_, SH_) do { if (part) FPOST(VT_, ND_, true, SH_); else FPOST(VT_, ND_, false, SH_); } while (0)
+#define FPOST(VT_, ND_, DOT_, SH_, XZ_)                                                                                      \
+  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_, XZ_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, \
+                     z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+#define FPOSTD(VT_, ND_, SH_)                                                                                              \
+  do {                                                                                                                     \
+    if (!xin) FPOST(VT_, ND_, false, SH_, true);                                                                          \
+    else if (part) FPOST(VT_, ND_, true, SH_, false);                                                                     \
+    else FPOST(VT_, ND_, false, SH_, false);                                                                              \
+  } while (0)
   if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
   else if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
   else { if (L.nd == 3) FPOSTD(float, 3, true); else FPOSTD(float, 4, true); }
@@ -1699,14 +1708,15 @@ __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, T
 template <typename TV>
 __global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, const double* __restrict__ rs,
                                                         double* __restrict__ x, double* __restrict__ part, int n,
-                                                        int Bp, int add = 0) {
+                                                        int Bp, int add = 0, const TV* __restrict__ e0 = nullptr) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double inv = rs ? 1.0 / rs[nm.b] : 1.0;  // the start was computed from the scaled right-hand side
   double s = 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double v = (double)x0[o] * inv + (add ? x[o] : 0.0);   // add: x0 is a correction of the caller's iterate
+    // add: x0 is a correction of the caller's iterate;  e0: the last cycle's correction of x0, not yet added (fmg_start)
+    const double v = ((double)x0[o] + (e0 ? (double)e0[o] : 0.0)) * inv + (add ? x[o] : 0.0);
     x[o] = v;
     s += v * v;
   }
@@ -2202,10 +2212,78 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   return xa;
 }
 
+// residual + full-weighting restriction of level l in one pass (the residual is never stored): H.rhs[l + 1] = R (rhs - A x)
+template <typename TV>
+void resid_restrict(const Hier& H, int l, const TV* x, const TV* rhs_l, hipStream_t st) {
+  const Level& L = H.lev[l];
+  const Level& C = H.lev[l + 1];
+  constexpr int CW = kRestrictCols;
+  bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
+  StripGeom g{true, 0, 0, 0};
+  g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int gy = H.Bp / (two ? 2 * kWave : kWave);
+    int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
+    if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+    if (nrc < 1) nrc = 1;
+    g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+    g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+    if (!two || strip2_tile_fits(L, H.Bp, 2 * g.TR + 1)) break;
+    two = false;                         // tiles beyond 32-bit offsets: the one-sample-per-lane kernel
+  }
+  Extra ex{};
+  ex.cW = C.W;
+  ex.bc = C.bc;
+  if (l == 0) kp_begin(KP_RESTRICT, st);
+  if (two)
+    launch_strip2<M_RESID, false, F_RESTRICT, 2 * CW + 1>(L, H.scale, (const float*)x, (const float*)rhs_l,
+                                                          (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
+  else
+    launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, x, rhs_l, (TV*)H.rhs[l + 1], 0.0, 0.0,
+                                                                   nullptr, H.Bp, g, st, ex);
+  if (l == 0) kp_end(KP_RESTRICT, st);
+}
+
+// Can level l of the fp32 cycle run the fused POST pass (and with it the initial-guess form of the cycle)?  Fills the
+// tile geometries of the fused PRE (gpre) and POST (gpost) passes; returns the fused_ok mask (0: no fused pass here).
+template <typename TV>
+int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
+  if (l >= H.nl - 1) return 0;
+  const Level& L = H.lev[l];
+  const Level& C = H.lev[l + 1];
+  const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
+  if (!fmask || !(L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use)) return 0;
+  const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
+  constexpr int CW = kRestrictCols;
+  StripGeom g{true, 0, 0, 0};
+  g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
+  const int gy = H.Bp / (spl * kWave);
+  int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
+  if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+  if (nrc < 1) nrc = 1;
+  g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
+  if (const int tr = env_level_int("DIFFHE_FUSED_TR_PRE", l)) g.TR = tr;
+  g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
+  *gpre = g;
+  *gpost = strip_geom(L, H.Bp, 4, spl);
+  if (const int tr = env_level_int("DIFFHE_FUSED_TR_POST", l)) {
+    if (gpost->ncb * ((L.ny + 1 + tr - 1) / tr) <= kPartBlocks) {
+      gpost->TR = tr;
+      gpost->nrc = (L.ny + 1 + tr - 1) / tr;
+    }
+  }
+  const bool fits = strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost->TR + 5);
+  return fits ? fmask : 0;
+}
+
 // z = V(rhs0): returns the buffer holding the result at level 0.  If rz_part != NULL the last
 // fine sweep also leaves the partials of rhs0.z there (*rz_blocks of them).
+// guess != NULL (only where fused_level(H, l0) & 2): the cycle starts from the initial guess P guess instead of 0 and
+// returns the new ITERATE for the right-hand side rhs0 -- in exact arithmetic P guess + V(rhs0 - A P guess), without the
+// prolongation, residual and addition passes of that form (full-multigrid start).
 template <typename TV>
-TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st, int l0 = 0) {
+TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipStream_t st, int l0 = 0,
+           const TV* guess = nullptr) {
   const TV* rhs[kMaxLevels];
   TV* cur[kMaxLevels];
   bool fused[kMaxLevels];
@@ -2225,40 +2303,30 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     TV* a = (TV*)H.xa[l];
     TV* b2 = (TV*)H.xb[l];
     fused[l] = false;
-    const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
+    StripGeom gpre;
+    const int fmask = fused_level<TV>(H, l, &gpre, &gpost[l]);
     if (fmask) {
-      // both sweeps + residual + restriction in ONE pass (fused_pre_kernel); the way up is fused_post_kernel
       const Level& C = H.lev[l + 1];
-      const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
-      if (L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use) {
-        constexpr int CW = kRestrictCols;
-        StripGeom g{true, 0, 0, 0};
-        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
-        const int gy = H.Bp / (spl * kWave);
-        int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
-        if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
-        if (nrc < 1) nrc = 1;
-        g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
-        if (const int tr = env_level_int("DIFFHE_FUSED_TR_PRE", l)) g.TR = tr;
-        g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
-        gpost[l] = strip_geom(L, H.Bp, 4, spl);
-        if (const int tr = env_level_int("DIFFHE_FUSED_TR_POST", l)) {
-          if (gpost[l].ncb * ((L.ny + 1 + tr - 1) / tr) <= kPartBlocks) {
-            gpost[l].TR = tr;
-            gpost[l].nrc = (L.ny + 1 + tr - 1) / tr;
-          }
-        }
-        const bool fits = strip2_tile_fits(L, H.Bp, 2 * g.TR + 6) && strip2_tile_fits(L, H.Bp, gpost[l].TR + 5);
-        fused[l] = fits && (fmask & 2);          // the way up: fused POST pass
-        if (fits && (fmask & 1)) {
-          if (l == 0) kp_begin(KP_FIRST2, st);
-          launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
-                           H.omega[1], H.Bp, g, spl, st);
-          if (l == 0) kp_end(KP_FIRST2, st);
-          cur[l] = a;
-          rhs[l + 1] = (const TV*)H.rhs[l + 1];
-          continue;
-        }
+      const int spl = H.Bv == 1 ? H.fuse : 2;
+      fused[l] = (fmask & 2) != 0;             // the way up: fused POST pass
+      if (l == l0 && guess && fused[l]) {
+        // two sweeps from the prolonged guess (the POST kernel with x = 0), then residual + restriction
+        launch_fused_post(L, C, H.Bv, H.scale, (const float*)nullptr, (const float*)rhs[l], (const float*)guess, (float*)a,
+                          H.omega[0], H.omega[1], nullptr, H.Bp, gpost[l], spl, st);
+        resid_restrict<TV>(H, l, a, rhs[l], st);
+        cur[l] = a;
+        rhs[l + 1] = (const TV*)H.rhs[l + 1];
+        continue;
+      }
+      if (fmask & 1) {
+        // both sweeps + residual + restriction in ONE pass (fused_pre_kernel)
+        if (l == 0) kp_begin(KP_FIRST2, st);
+        launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
+                         H.omega[1], H.Bp, gpre, spl, st);
+        if (l == 0) kp_end(KP_FIRST2, st);
+        cur[l] = a;
+        rhs[l + 1] = (const TV*)H.rhs[l + 1];
+        continue;
       }
     }
     int done;
@@ -2284,32 +2352,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     if (l < last) {
       const Level& C = H.lev[l + 1];
       if (strip_geom(L, H.Bp).use && L.nx == 2 * C.nx && L.ny == 2 * C.ny) {
-        // residual + full-weighting restriction in one pass: the residual is never stored
-        constexpr int CW = kRestrictCols;
-        bool two = sizeof(TV) == 4 && strip2_ok(L, H.Bv, H.Bp);
-        StripGeom g{true, 0, 0, 0};
-        g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
-        for (int pass = 0; pass < 2; ++pass) {
-          const int gy = H.Bp / (two ? 2 * kWave : kWave);
-          int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
-          if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
-          if (nrc < 1) nrc = 1;
-          g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
-          g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
-          if (!two || strip2_tile_fits(L, H.Bp, 2 * g.TR + 1)) break;
-          two = false;                         // tiles beyond 32-bit offsets: the one-sample-per-lane kernel
-        }
-        Extra ex{};
-        ex.cW = C.W;
-        ex.bc = C.bc;
-        if (l == 0) kp_begin(KP_RESTRICT, st);
-        if (two)
-          launch_strip2<M_RESID, false, F_RESTRICT, 2 * CW + 1>(L, H.scale, (const float*)a, (const float*)rhs[l],
-                                                                (float*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
-        else
-          launch_strip<TV, M_RESID, false, F_RESTRICT, TV, 2 * CW + 1>(L, H.Bv, H.scale, (const TV*)a, rhs[l],
-                                                                         (TV*)H.rhs[l + 1], 0.0, 0.0, nullptr, H.Bp, g, st, ex);
-        if (l == 0) kp_end(KP_RESTRICT, st);
+        resid_restrict<TV>(H, l, a, rhs[l], st);
       } else {
         op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
         LAUNCH(((double)L.n / C.n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
@@ -2368,8 +2411,10 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
 // Full multigrid start: solve on the coarsest level, then per level interpolate, take the residual
 // and apply one V-cycle.  Gives the CG an iterate whose error is already smooth (about 3-4 CG
 // iterations ahead of a zero guess) for ~0.8 of an iteration.  b0 = right-hand side in TV storage.
+// *pending (optional): the fine level's last correction is NOT added to the returned iterate but handed back -- the
+// caller's conversion pass (pcg_setx_kernel) adds the two in fp64, one pass over x less.
 template <typename TV>
-TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
+TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st, const TV** pending = nullptr) {
   const int last = H.nl - 1;
   const TV* bl[kMaxLevels];
   bl[0] = b0;
@@ -2382,19 +2427,44 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st) {
     if (diffhe::check(hipMemcpyAsync(H.xF[last], e, (size_t)H.lev[last].n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st)))
       return nullptr;  // error text recorded for diffhe_last_hip_error()
   }
+  const TV* coarse = (const TV*)H.xF[last];      // the iterate of level l + 1
+  if (pending) *pending = nullptr;
+  // 2: the initial-guess form of the cycle below the fine level only.  On the fine level it stores the full ITERATE in
+  // fp32 between its passes where the correction form stores a correction ~1e-3 of it: rounding noise of 6e-8 |u|, rough,
+  // ~3e-5 of the solution's energy -- measured one PCG iteration more (6 + 6 against 5 + 5 at 1024^2; gpurun_out/r4m)
+  static const int guess_form = getenv("DIFFHE_FMG_GUESS") ? atoi(getenv("DIFFHE_FMG_GUESS")) : 2;
   for (int l = last - 1; l >= 0; --l) {
     const Level& L = H.lev[l];
-    TV* x = (TV*)H.xF[l];
-    LAUNCH((1.0 + (double)H.lev[l + 1].n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], (const TV*)H.xF[l + 1], x, H.Bp, 1);
     const int cycles = (l == 0) ? 1 : H.fmg_coarse_cycles;  // extra cycles on the cheap coarse levels
-    for (int c = 0; c < cycles; ++c) {
+    StripGeom g1, g2;
+    TV* x = (TV*)H.xF[l];
+    int c0 = 0;
+    if (guess_form && (l > 0 || guess_form == 1) && (fused_level<TV>(H, l, &g1, &g2) & 2)) {
+      // levels with the fused passes: ONE cycle from the prolonged guess -- no prolongation, residual or addition pass
+      TV* it = vcycle<TV>(H, bl[l], nullptr, nullptr, st, l, coarse);
+      if (cycles == 1) {
+        coarse = it;          // consumed by the first launch of the next level, before that level's cycle reuses the buffer
+        continue;
+      }
+      if (diffhe::check(hipMemcpyAsync(x, it, (size_t)L.n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st))) return nullptr;
+      c0 = 1;
+    } else {
+      LAUNCH((1.0 + (double)H.lev[l + 1].n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], coarse, x, H.Bp, 1);
+    }
+    for (int c = c0; c < cycles; ++c) {
       op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
       TV* e = vcycle<TV>(H, (const TV*)H.rhs[l], nullptr, nullptr, st, l);
+      if (l == 0 && c == cycles - 1 && pending) {
+        *pending = e;
+        break;
+      }
       LAUNCH(3 * sizeof(TV), mg_add_kernel<TV>, L.n, (const TV*)e, x, L.n, H.Bp);
     }
+    coarse = x;
   }
-  return (TV*)H.xF[0];
+  return (TV*)coarse;
 }
+
 
 }  // namespace
 
@@ -2690,15 +2760,17 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     // close, times the ~1e-3 of the full-multigrid step itself.
     if (warm) residual_pass(false);
     if (f32) {
-      const float* x0 = fmg_start<float>(H, (const float*)r32, st);
+      const float* e0 = nullptr;
+      const float* x0 = fmg_start<float>(H, (const float*)r32, st, &e0);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(warm ? 20.0 : 12.0, pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x,
-             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0);
+      LAUNCH((warm ? 20.0 : 12.0) + (e0 ? 4.0 : 0.0), pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x,
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0);
     } else {
-      const double* x0 = fmg_start<double>(H, warm ? (const double*)r : b, st);
+      const double* e0 = nullptr;
+      const double* x0 = fmg_start<double>(H, warm ? (const double*)r : b, st, &e0);
       if (!x0) return DIFFHE_E_LAUNCH;
-      LAUNCH(warm ? 24.0 : 16.0, pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x,
-             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0);
+      LAUNCH((warm ? 24.0 : 16.0) + (e0 ? 8.0 : 0.0), pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x,
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0);
     }
     if (use_floor) SCALAR(S_FLOOR, partA, nblk);
     residual_pass(true);

@@ -19,7 +19,8 @@ def main():
     rows = []
     with open(sys.argv[1]) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+            grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y"))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]) + " [" + grid + "]"))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "pcg_update_kernel" in r[2]]
     # steps: pcg_update launches come in bursts of (fwd its + adj its); split bursts by gaps > 20 ms
@@ -44,7 +45,7 @@ def main():
         per[n_][2] = max(per[n_][2], (e_ - s_) / 1e6)
     print("kernel time inside the window:")
     acc = 0.0
-    for n_, (c, t, mx) in sorted(per.items(), key=lambda kv: -kv[1][1])[:40]:
+    for n_, (c, t, mx) in sorted(per.items(), key=lambda kv: -kv[1][1])[:60]:
         acc += t
         print(f"  {t:7.3f} ms ({100 * t / busy:5.1f} %, cum {100 * acc / busy:5.1f})  n={c:4d}  max {mx:6.3f}  {n_}")
     gaps = []

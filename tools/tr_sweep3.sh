@@ -1,0 +1,14 @@
+#!/bin/bash
+out=${1:-gpurun_out/trsweep3}; mkdir -p $out
+run() {  # label, env...
+  label=$1; shift
+  env "$@" timeout -k 10 120 python bench.py --no-variants --no-cpu-baseline --steps 8 --warmup 2 --kernel-reps 1 > $out/$label.json 2> $out/$label.err || { echo "$label FAILED"; tail -3 $out/$label.err; return 1; }
+  python - $out/$label.json $label <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in d["roofline"]["other_kernels"]}
+print(f"{sys.argv[2]:28s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  pre {o.get('fused_pre_kernel')}  post {o.get('fused_post_kernel')}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e}", flush=True)
+PY
+}
+run default X=1
+run old DIFFHE_FMG_GUESS=0 DIFFHE_STRIP_MINW=192
