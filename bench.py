@@ -480,13 +480,16 @@ KERNEL_NAMES_FUSED = [KERNEL_NAMES[0], KERNEL_NAMES[1],
                       KERNEL_NAMES[5]]
 
 
-def kernel_table(kprof, n, Bp, f32, fused=False):
+def kernel_table(kprof, n, Bp, f32, fused=False, rupd=False):
     """Per-kernel roofline rows from the in-solver HIP-event totals (fine level, forward solves)."""
     tv = 4.0 if f32 else 8.0
     bytes_ = [(3 * tv + 8.0), 24.0 + (4.0 if f32 else 0.0), 2.0 * tv, 2.25 * tv, 3.25 * tv, 3.0 * tv]
-    names = KERNEL_NAMES
+    names = list(KERNEL_NAMES)
     if fused and f32:
-        bytes_[2], bytes_[4], names = 9.0, 13.0, KERNEL_NAMES_FUSED
+        bytes_[2], bytes_[4], names = 9.0, 13.0, list(KERNEL_NAMES_FUSED)
+    if rupd and f32:   # A p never stored: CG step z, p_old in, p out; residual update p, r in, r and its fp32 copy out
+        bytes_[0], bytes_[1] = 12.0, 24.0
+        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, KERNEL_NAME_RUPD
     rows = []
     for nm, bpn, (ms_, n_) in zip(names, bytes_, kprof):
         if n_ > 0:
@@ -707,6 +710,11 @@ KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, f
                        "dia_strip_kernel<float, float, double, 2, 0, 3, true, false, 4, 1>"]
 
 
+KERNEL_NAME_CGSTEP_NOAP = "fused CG step: p = z + beta p stored, p.Ap with A p kept in registers (never stored; 12 B)"
+KERNEL_NAME_RUPD = "residual update with A p recomputed from the stored p: r -= alpha A p, r.r, fp32 copy of r (24 B)"
+KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, false, 4, 5>"
+
+
 KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true>",
                         KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true>", KERNEL_SYMBOLS_FP32[5]]
 
@@ -721,13 +729,19 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
         return None
     f32 = bool(solver.mg.get("fp32"))
     fused = bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0 and bool(solver.mg.get("fused", 1))
-    table = kernel_table(kprof, n, Bp, f32, fused)
+    rupd = bool(L.diffhe_lattice_recompute_ap()) and f32
+    table = kernel_table(kprof, n, Bp, f32, fused, rupd)
     if not table:
         return None
-    symbols = KERNEL_SYMBOLS_FUSED if fused else KERNEL_SYMBOLS_FP32
+    symbols = list(KERNEL_SYMBOLS_FUSED if fused else KERNEL_SYMBOLS_FP32)
+    if rupd:
+        symbols[1] = KERNEL_SYMBOL_RUPD
     have = [sy for sy, (ms_, n_) in zip(symbols, kprof) if n_ > 0]
     traffic, src = pmc_traffic(have, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")
-    by_name = dict(zip(KERNEL_NAMES_FUSED if fused else KERNEL_NAMES, symbols))
+    names = list(KERNEL_NAMES_FUSED if fused else KERNEL_NAMES)
+    if rupd:
+        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, KERNEL_NAME_RUPD
+    by_name = dict(zip(names, symbols))
     for row in table:
         row["symbol"] = by_name[row["kernel"]] if f32 else None
         row["traffic"] = traffic.get(row["symbol"]) if f32 else None

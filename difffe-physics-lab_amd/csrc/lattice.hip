@@ -186,7 +186,10 @@ enum { M_APPLY = 0, M_RESID = 1, M_JACOBI = 2 };
 //              columns 2 J0 - 1 .. 2 J0 + 2 CW - 1 that feed the wave's CW coarse columns (one fine
 //              column is shared with -- and recomputed by -- each neighbour strip) and the tile the
 //              fine rows 2 I0 - 1 .. 2 I1 - 1 of the coarse rows I0 .. I1 - 1.
-enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2, F_RESTRICT = 3, F_PUPD_NX = 4 };
+enum { F_NONE = 0, F_PROLONG = 1, F_PUPD = 2, F_RESTRICT = 3, F_PUPD_NX = 4, F_RUPD = 5 };
+// F_RUPD (with M_APPLY): the CG's residual update with A p RECOMPUTED from the stored direction p (TA, ex.p_in) instead of
+// read back: r -= alpha (A p), the fp32 copy of r and the partials of r.r in one pass -- for a batch-shared matrix (scalar
+// loads, no coefficient traffic) reading p's window (4 B + halo) is cheaper than writing and re-reading A p (8 + 8 B).
 // F_PUPD_NX: F_PUPD without the iterate update (the solver's form: x is assembled from the kept directions at the
 // end); a compile-time variant so that the x stream costs neither registers nor instructions
 constexpr bool is_pupd(int fuse) { return fuse == F_PUPD || fuse == F_PUPD_NX; }
@@ -267,7 +270,11 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   const TA* __restrict__ aux = (const TA*)ex.a0;
   // F_PUPD row pointers at (row, c0w), advanced with the others
   const TA* __restrict__ pz = (is_pupd(FUSE)) ? aux + i0 * Bp : nullptr;
-  const TA* __restrict__ ppi = (is_pupd(FUSE)) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
+  const TA* __restrict__ ppi = (is_pupd(FUSE) || FUSE == F_RUPD) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
+  double* __restrict__ pr = (FUSE == F_RUPD) ? ex.x + i0 * Bp : nullptr;          // F_RUPD: ex.x is the residual r
+  float* __restrict__ pr32 = (FUSE == F_RUPD && ex.r32) ? ex.r32 + i0 * Bp : nullptr;
+  const double alpha_cur = (FUSE == F_RUPD) ? ex.alpha[b] : 0.0;
+  const double rsc_u = (FUSE == F_RUPD && ex.r32 && ex.rscale) ? ex.rscale[b] : 1.0;
   TA* __restrict__ ppo = (is_pupd(FUSE)) ? (TA*)ex.p_out + i0 * Bp : nullptr;
   double* __restrict__ pxx = (FUSE == F_PUPD && ex.x) ? ex.x + i0 * Bp : nullptr;  // NULL: the iterate is not touched
 
@@ -296,6 +303,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         // the direction is STORED as TA: use the stored (rounded) value everywhere, so that Ap = A p,
         // x += alpha p and r -= alpha Ap stay exactly consistent (r == b - A x is independent of p)
         v = (double)(TA)v;
+      } else if (FUSE == F_RUPD) {
+        v = (double)(ppi + roff + (i64)dq[q] * Bp)[lb];
       } else {
         v = (double)(xrow + (i64)dq[q] * Bp)[lb];
       }
@@ -369,7 +378,13 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       const double sh = SHIFT ? psh[dq[k + 1]] : 0.0;   // A = sb K + diag(shift)
       const double diag = SHIFT ? sb * d0[k] + sh : sb * d0[k];
       const double Ax = SHIFT ? sb * acc + sh * xc[q] : sb * acc;
-      if (MODE == M_APPLY) {
+      if (MODE == M_APPLY && FUSE == F_RUPD) {
+        double* ra = &(pr + o)[lb];
+        const double ri = __builtin_nontemporal_load(ra) - alpha_cur * Ax;
+        __builtin_nontemporal_store(ri, ra);
+        if (pr32) (pr32 + o)[lb] = (float)(ri * rsc_u);   // read again right away by the V-cycle: left cacheable
+        s += ri * ri;
+      } else if (MODE == M_APPLY) {
         double y = Ax;
         if (FUSE == F_NONE && (ex.sub || ex.mask)) {  // load vector of a lattice mesh: F = M f - lift, 0 on Dirichlet rows
           const i64 ig = (i64)row * W + c0w + k;
@@ -466,6 +481,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     if (pb) pb += rowX;
     if (po) po += rowX;
     if (is_pupd(FUSE)) { pz += rowX; ppi += rowX; ppo += rowX; if (FUSE == F_PUPD && pxx) pxx += rowX; }
+    if (FUSE == F_RUPD) { ppi += rowX; pr += rowX; if (pr32) pr32 += rowX; }
   }
   return s;
 }
@@ -1358,7 +1374,8 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
     double bpn;
     if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * tv + (FUSE == F_PROLONG ? 0.25 * tv : 0.0);
     else if (MODE == M_RESID) bpn = 2.0 * tv + (FUSE == F_RESTRICT ? 0.25 * tv : (out ? tv : 0.0) + (ex.r32 ? 4.0 : 0.0));
-    else if (is_pupd(FUSE)) bpn = ex.first ? 2.0 * ta + 8.0 : 3.0 * ta + 8.0 + ((FUSE == F_PUPD && ex.x) ? 16.0 : 0.0);
+    else if (is_pupd(FUSE)) bpn = (ex.first ? 2.0 * ta : 3.0 * ta) + (out ? 8.0 : 0.0) + ((FUSE == F_PUPD && ex.x) ? 16.0 : 0.0);
+    else if (FUSE == F_RUPD) bpn = ta + 16.0 + (ex.r32 ? 4.0 : 0.0);
     else bpn = tv + (out ? tv : 0.0) + (ex.dotv ? 8.0 : 0.0);
     if (Bv != 1) bpn += m16 ? 4.0 + 2.0 * (L.nd - 1) : L.nd * (m32 ? 4.0 : 8.0);
     diffhe::account(bpn * (double)L.n * Bp);
@@ -1444,6 +1461,13 @@ inline unsigned fused_lds() {
 // per-sample matrix with the compact copies (fp32 diagonal + scaled fp16 off-diagonals) and the mask, no per-sample scale
 // returns a bit mask: 1 = the PRE pass may be fused, 2 = the POST pass
 // development knob: "a:b:c" = one integer per multigrid level (0 / missing = keep the default)
+// DIFFHE_RUPD: 0 = store A p and read it back in pcg_update_kernel; 1 = recompute it in the residual update (F_RUPD);
+// 2 / 4 = the same with other launch shapes (development)
+inline int rupd_env() {
+  static const int v = getenv("DIFFHE_RUPD") ? atoi(getenv("DIFFHE_RUPD")) : 1;
+  return v;
+}
+
 inline int env_level_int(const char* name, int level) {
   const char* e = getenv(name);
   if (!e) return 0;
@@ -2677,6 +2701,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   static const int pupd_variant = getenv("DIFFHE_PUPD_VARIANT") ? atoi(getenv("DIFFHE_PUPD_VARIANT")) : 0;
   const StripGeom g0 = strip_geom(L0, Bp, kPupdCols);
   const bool fused = g0.use;
+  // batch-shared matrix, fp32-stored directions: A p is never stored -- the residual update recomputes it from p (F_RUPD)
+  const int rupd_mode = rupd_env();
+  const bool rupd = fused && f32 && Bv == 1 && rupd_mode != 0;
+  const StripGeom g8 = strip_geom(L0, Bp, 8);
   const void* z = nullptr;
   int it = 0, flushed = 0;       // iterations done / directions already folded into x (fused loop)
   // x += sum_{j = flushed .. it-1} alpha_j p_j  (+ z / rs at the end of the solve: pcg_finish_kernel)
@@ -2711,7 +2739,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       ex.alpha = nullptr; ex.beta = S.beta; ex.first = first;
 #define NXV(RW_, MINW_)                                                                                               \
   launch_strip<double, M_APPLY, false, F_PUPD_NX, float, RW_, MINW_>(L0, Bv, scale, (const double*)nullptr,                \
-                                                                      (const double*)nullptr, Ap, 0.0, 0.0, partA, Bp, g0, st, ex)
+                                                                      (const double*)nullptr, rupd ? (double*)nullptr : Ap, \
+                                                                      0.0, 0.0, partA, Bp, g0, st, ex)
       if (f32) {
         // 72 VGPRs (18 spilled), 7 waves per SIMD: 1.16 ms against 1.28 at the compiler's own 85 / 5; 8-column strips
         // (142 VGPRs) 1.96, 2-column strips at 8 waves 1.27, 6 or 8 waves 1.25 / 1.18 (same box, gpurun_out/r2l/variants*.txt).
@@ -2786,10 +2815,26 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     apply_step(it == 0);
     SCALAR(S_ALPHA, partA, nba);
     kp_begin(KP_UPDATE, st);
-    LAUNCH(24.0 + (r32 ? 4.0 : 0.0) + (fused ? 0.0 : 24.0), pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
-           r, r32, (const double*)S.rs, partA, n, Bp);
+    if (rupd) {
+      Extra ex{};
+      ex.p_in = (char*)p + (size_t)(it % n_slots) * slot_stride * sizeof(float);   // the direction apply_step just stored
+      ex.x = r;
+      ex.r32 = r32;
+      ex.rscale = S.rs;
+      ex.alpha = S.alpha;
+#define RUV(RW_, MINW_, G_)                                                                                            \
+  launch_strip<double, M_APPLY, false, F_RUPD, float, RW_, MINW_>(L0, Bv, scale, (const double*)nullptr,                   \
+                                                                   (const double*)nullptr, (double*)nullptr, 0.0, 0.0,   \
+                                                                   partA, Bp, G_, st, ex)
+      // 5 waves per SIMD: 1.30 ms at 1024^2 x 256 (compiler's own choice 1.30, 7 waves 2.31 with spills; gpurun_out/r4q)
+      if (rupd_mode == 2) RUV(kPupdCols, 1, g0); else if (rupd_mode == 4) RUV(8, 1, g8); else RUV(kPupdCols, 5, g0);
+#undef RUV
+    } else {
+      LAUNCH(24.0 + (r32 ? 4.0 : 0.0) + (fused ? 0.0 : 24.0), pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
+             r, r32, (const double*)S.rs, partA, n, Bp);
+    }
     kp_end(KP_UPDATE, st);
-    SCALAR(S_CONV, partA, nblk);
+    SCALAR(S_CONV, partA, rupd ? (rupd_mode == 4 ? g8.ncb * g8.nrc : g0.ncb * g0.nrc) : nblk);
     ++it;
     // z = V(r) and r.z: the new search direction's ingredients AND the energy-norm error estimate of the iterate;
     // the samples still active are counted in the scalar phase behind it (S_BETA)
@@ -2815,6 +2860,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   status_host[1] = n_active < 0 ? 0 : n_active;
   return DIFFHE_OK;
 }
+
+extern "C" int diffhe_lattice_recompute_ap(void) { return rupd_env() != 0; }
 
 extern "C" int diffhe_lattice_blocks(int n, int Bp) { (void)n; (void)Bp; return kPartBlocks; }
 

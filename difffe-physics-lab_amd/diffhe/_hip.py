@@ -62,6 +62,7 @@ SIGNATURES = {
     "diffhe_lattice_kernel_profile": (_I, [_I, C.POINTER(_D), C.POINTER(_L)]),
     "diffhe_lattice_blocks": (_I, [_I, _I]),
     "diffhe_lattice_fused_passes": (_I, []),
+    "diffhe_lattice_recompute_ap": (_I, []),
     "diffhe_lattice_apply": (_I, [_LV, _I, _P, _P, _P, _P, _I, _P]),
     "diffhe_lattice_smooth": (_I, [_LV, _I, _P, _P, _P, _P, _D, _I, _P]),
     "diffhe_lattice_cg_step": (_I, [_LV, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),

@@ -320,6 +320,11 @@ int diffhe_lattice_blocks(int n, int Bp);
  * With them, kernel-profile id 2 times the fused PRE pass (9 B per node and sample), id 4 the fused POST pass (13 B),
  * ids 3 and 5 see no launches. */
 int diffhe_lattice_fused_passes(void);
+/* 1: with a batch-shared matrix and fp32-stored search directions the PCG never stores A p -- the fused CG step keeps it
+ * in registers for p.Ap (12 B per node and sample: z, p_old read, p written) and the residual update recomputes it from
+ * the stored p (24 B: p, r read; r and its fp32 copy written; kernel-profile id 1).  0 (environment DIFFHE_RUPD=0): A p
+ * is written by the CG step (20 B) and read back by pcg_update_kernel (28 B). */
+int diffhe_lattice_recompute_ap(void);
 int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x, double* y,
                          double* part, int Bp, void* stream);
 int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const double* scale, const double* rhs,

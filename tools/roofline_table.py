@@ -14,7 +14,8 @@ N, BP = 1025 * 1025, 256
 PASS = 8.0 * N * BP
 # (substring of the kernel name, template-argument pattern) -> (label, algorithmic passes per launch)
 RULES = [
-    ("dia_strip_kernel<double, float, double, 0, 4", "fused CG step (p = z + beta p, A p, dot; x formed at the end), z/p fp32", 2.5),
+    ("dia_strip_kernel<double, float, double, 0, 4", "fused CG step (p = z + beta p stored, p.Ap; A p kept in registers, x formed at the end), z/p fp32", 1.5),
+    ("dia_strip_kernel<double, float, double, 0, 5", "residual update, A p recomputed from p: r -= alpha A p, r.r, fp32 copy of r", 3.0),
     ("dia_strip_kernel<double, double, double, 0, 4", "fused CG step, z/p fp64", 4.0),
     ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step with the x update (isolated launches of bench.py only)", 4.5),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),

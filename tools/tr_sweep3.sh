@@ -6,9 +6,13 @@ run() {  # label, env...
   python - $out/$label.json $label <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in d["roofline"]["other_kernels"]}
-print(f"{sys.argv[2]:28s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  pre {o.get('fused_pre_kernel')}  post {o.get('fused_post_kernel')}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e}", flush=True)
+r = d["roofline"]
+o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in r["other_kernels"]}
+print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  update {r['avg_launch_ms']}  others {o}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run default X=1
-run old DIFFHE_FMG_GUESS=0 DIFFHE_STRIP_MINW=192
+run rupd1 DIFFHE_RUPD=1
+run rupd4 DIFFHE_RUPD=4
+run rupd1_pv5 DIFFHE_RUPD=1 DIFFHE_PUPD_VARIANT=5
+run rupd2 DIFFHE_RUPD=2
+run rupd1b DIFFHE_RUPD=1
