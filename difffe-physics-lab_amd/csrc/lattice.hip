@@ -2745,7 +2745,11 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
         // 72 VGPRs (18 spilled), 7 waves per SIMD: 1.16 ms against 1.28 at the compiler's own 85 / 5; 8-column strips
         // (142 VGPRs) 1.96, 2-column strips at 8 waves 1.27, 6 or 8 waves 1.25 / 1.18 (same box, gpurun_out/r2l/variants*.txt).
         // The same cap on the V-cycle's strip kernels (already 6-7 waves) made them slower: -2...-6 % end to end.
-        if (pupd_variant == 5) NXV(4, 1); else NXV(4, 7);
+        // per-sample matrices (coefficients in VGPRs): 4 waves per SIMD, 245.2 ms per step of the per-element-field variant
+        // against 249.5 at 7 (gpurun_out/r4w)
+        static const int pupd_ps = getenv("DIFFHE_PUPD_PS") ? atoi(getenv("DIFFHE_PUPD_PS")) : 4;
+        const int pv = Bv != 1 ? pupd_ps : pupd_variant;
+        if (pv == 5 || pv == 1) NXV(4, 1); else if (pv == 4) NXV(4, 4); else if (pv == 6) NXV(4, 6); else NXV(4, 7);
       }
 #undef NXV
       else

@@ -22,7 +22,7 @@ def main():
             grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y"))
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]) + " [" + grid + "]"))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "pcg_update_kernel" in r[2]]
+    marks = [i for i, r in enumerate(rows) if "pcg_update_kernel" in r[2] or "double, float, double, 0, 5," in r[2]]
     # steps: pcg_update launches come in bursts of (fwd its + adj its); split bursts by gaps > 20 ms
     starts = [marks[0]]
     for a, b in zip(marks, marks[1:]):

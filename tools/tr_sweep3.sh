@@ -11,8 +11,7 @@ o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in r["other_kernels"]}
 print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  update {r['avg_launch_ms']}  others {o}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run rupd1 DIFFHE_RUPD=1
-run rupd4 DIFFHE_RUPD=4
-run rupd1_pv5 DIFFHE_RUPD=1 DIFFHE_PUPD_VARIANT=5
-run rupd2 DIFFHE_RUPD=2
-run rupd1b DIFFHE_RUPD=1
+run base X=1
+run pv6 DIFFHE_PUPD_VARIANT=6
+run pv8 DIFFHE_PUPD_VARIANT=8
+run base2 X=1
