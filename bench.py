@@ -565,7 +565,8 @@ def variant_config2(args, torch, L, _hip, ctypes, dev, timed):
 
 
 def _lattice_variant_roofline(L, ctypes, n, Bp, f32):
-    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0)
+    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0,
+                        rupd=bool(L.diffhe_lattice_recompute_ap()) and f32)
     if not rows:
         return None
     top = dict(rows[0])
@@ -716,7 +717,7 @@ KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, fal
 
 
 KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true>",
-                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true>", KERNEL_SYMBOLS_FP32[5]]
+                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true, false>", KERNEL_SYMBOLS_FP32[5]]
 
 
 def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, prof_n, kprof=()):
