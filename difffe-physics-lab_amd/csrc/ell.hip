@@ -108,6 +108,73 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The same gather for FEMesh.rectangle connectivity, lists written into the code (diffhe/plan.py: build_dia_pattern):
+// quad (r, c), q = r nx + c, holds T0 = [a, b, d] = element 2q and T1 = [b, c, d] = element 2q + 1; node (r, c) sees the
+// six triangles A = T1(r-1,c-1), B = T0(r-1,c), C = T1(r-1,c), D = T0(r,c-1), E = T1(r,c-1), F = T0(r,c).  Same
+// contributions, same element order, same fma chain as assemble_rows_kernel<false> -- bitwise the same values -- but
+// no index lists to read, each kappa_e loaded once per node (six loads, wave-uniform addresses + lane = sample) instead
+// of once per contribution (up to 18), local integrals as scalar loads.  One wave per node, lanes over samples.
+// Seven entry kinds per row in the order (0, +1, +W, +nx, -1, -W, -nx); the first nd are stored, the others only feed
+// the Dirichlet lift.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __restrict__ local,
+                                                                const double* __restrict__ kappa, i64 kse, i64 ksb,
+                                                                const unsigned char* __restrict__ is_bc,
+                                                                const double* __restrict__ g, double* __restrict__ vals,
+                                                                double* __restrict__ lift, int nx, int ny, int nd,
+                                                                int Bv) {
+#pragma clang fp contract(off)
+  const NodeMap nm = node_map(Bv);
+  if (nm.b >= Bv) return;
+  const int W = nx + 1;
+  const i64 n = (i64)W * (ny + 1), m = 2 * (i64)nx * ny;
+  const i64 kb = (i64)nm.b * ksb;
+  for (int i = nm.node0; i < n; i += nm.stride) {
+    const int r = i / W, c = i - r * W;
+    const bool up = r < ny, dn = r >= 1, lf = c >= 1, rt = c < nx;
+    // element ids (valid only under their masks)
+    const i64 eA = 2 * ((i64)(r - 1) * nx + (c - 1)) + 1, eB = 2 * ((i64)(r - 1) * nx + c), eC = eB + 1;
+    const i64 eD = 2 * ((i64)r * nx + (c - 1)), eE = eD + 1, eF = 2 * ((i64)r * nx + c);
+    const bool hA = dn && lf, hBC = dn && rt, hDE = up && lf, hF = up && rt;
+    const double kA = hA ? (kappa ? kappa[eA * kse + kb] : 1.0) : 0.0;
+    const double kB = hBC ? (kappa ? kappa[eB * kse + kb] : 1.0) : 0.0;
+    const double kC = hBC ? (kappa ? kappa[eC * kse + kb] : 1.0) : 0.0;
+    const double kD = hDE ? (kappa ? kappa[eD * kse + kb] : 1.0) : 0.0;
+    const double kE = hDE ? (kappa ? kappa[eE * kse + kb] : 1.0) : 0.0;
+    const double kF = hF ? (kappa ? kappa[eF * kse + kb] : 1.0) : 0.0;
+    auto loc = [&](int pq, i64 e) -> double { return local[(i64)pq * m + e]; };
+    const bool row_bc = is_bc && is_bc[i];
+    double lfv = 0.0;
+    // entry kinds: offsets and contribution lists (mask, element, kappa, local entry), increasing element id
+#define CONTRIB(mask_, k_, pq_, e_) if (mask_) v = fma((k_), loc((pq_), (e_)), v)
+#define ENTRY(kind_, off_, any_, BODY)                                                        \
+    {                                                                                         \
+      const int store = (kind_) < nd ? (kind_) : -1;                                          \
+      const i64 j = (any_) ? (i64)i + (off_) : (i64)i;                                        \
+      const bool col_bc = is_bc && j != i && is_bc[j];                                        \
+      if (!(store < 0 && (row_bc || !col_bc))) {                                              \
+        double v = 0.0;                                                                       \
+        BODY                                                                                  \
+        if (row_bc) v = ((kind_) == 0) ? 1.0 : 0.0;                                           \
+        else if (col_bc) { lfv += v * g[j]; v = 0.0; }                                        \
+        if (store >= 0) vals[((i64)store * n + i) * Bv + nm.b] = v;                           \
+      }                                                                                       \
+    }
+    ENTRY(0, 0, true, CONTRIB(hA, kA, 4, eA); CONTRIB(hBC, kB, 8, eB); CONTRIB(hBC, kC, 8, eC); CONTRIB(hDE, kD, 4, eD);
+          CONTRIB(hDE, kE, 0, eE); CONTRIB(hF, kF, 0, eF);)
+    ENTRY(1, 1, rt, CONTRIB(rt && dn, kC, 7, eC); CONTRIB(rt && up, kF, 1, eF);)
+    ENTRY(2, W, up, CONTRIB(up && lf, kE, 1, eE); CONTRIB(up && rt, kF, 2, eF);)
+    ENTRY(3, nx, up && lf, CONTRIB(up && lf, kD, 5, eD); CONTRIB(up && lf, kE, 2, eE);)
+    ENTRY(4, -1, lf, CONTRIB(lf && dn, kA, 5, eA); CONTRIB(lf && up, kD, 3, eD);)
+    ENTRY(5, -W, dn, CONTRIB(dn && lf, kA, 3, eA); CONTRIB(dn && rt, kB, 6, eB);)
+    ENTRY(6, -nx, dn && rt, CONTRIB(dn && rt, kB, 7, eB); CONTRIB(dn && rt, kC, 6, eC);)
+#undef ENTRY
+#undef CONTRIB
+    if (lift) lift[(i64)i * Bv + nm.b] = lfv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Element-parallel assembly with fp64 atomics; element integrals staged in LDS
 // ---------------------------------------------------------------------------------------
 constexpr int kElemTile = 64;
@@ -878,6 +945,20 @@ extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa
   hipLaunchKernelGGL(assemble_rows_kernel<false>, diffhe::node_grid(n, Bv), dim3(256), 0, (hipStream_t)stream, local,
                      (const double*)nullptr, kappa, kappa_se, kappa_sb, ent_ptr, contrib, cols, store_slot, is_bc, g,
                      vals, lift, n, m, W, Bv);
+  return diffhe::check_launch();
+}
+
+extern "C" int diffhe_lattice_assemble_rows(const double* local, const double* kappa, long long kappa_se,
+                                            long long kappa_sb, const unsigned char* is_bc, const double* g,
+                                            double* vals, double* lift, int nx, int ny, int nd, int Bv, void* stream) {
+  if (!local || !vals || nx < 1 || ny < 1 || nd < 3 || nd > 4) return DIFFHE_E_BADARG;
+  if (is_bc && !g) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  const long long n = (long long)(nx + 1) * (ny + 1), m = 2LL * nx * ny;
+  if (n > 2147483647LL) return DIFFHE_E_BADARG;
+  diffhe::account(8.0 * Bv * ((double)nd * n + (lift ? n : 0) + ((kappa && kappa_se) ? m : 0)));
+  hipLaunchKernelGGL(lattice_assemble_kernel, diffhe::node_grid((int)n, Bv), dim3(256), 0, (hipStream_t)stream, local, kappa,
+                     kappa_se, kappa_sb, is_bc, g, vals, lift, nx, ny, nd, Bv);
   return diffhe::check_launch();
 }
 

@@ -13,6 +13,7 @@
 // optional per-sample scale s_b on the free rows, K_b = s_b * K_1 -- the exact form of the
 // assembled operator when kappa is one scalar per sample (solver.py:88,139: k_e = kappa * k0_e).
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "common.h"
@@ -942,6 +943,18 @@ __device__ __forceinline__ v2f ldh(rsrc_t r, unsigned voff, v2f) {
   const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
   return v2f{(float)h.x, (float)h.y};
 }
+__device__ __forceinline__ unsigned ldraw(rsrc_t r, unsigned voff, float) {
+  return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
+}
+__device__ __forceinline__ unsigned ldraw(rsrc_t r, unsigned voff, v2f) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+}
+__device__ __forceinline__ float unraw(unsigned raw, float) { return (float)__builtin_bit_cast(_Float16, (unsigned short)raw); }
+__device__ __forceinline__ v2f unraw(unsigned raw, v2f) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h = __builtin_bit_cast(h2, raw);
+  return v2f{(float)h.x, (float)h.y};
+}
 template <typename VT> struct Coef<VT, false> {
   typedef VT T;
   rsrc_t r0, r1, r2, r3;
@@ -962,6 +975,10 @@ template <typename VT> struct Coef<VT, false> {
   __device__ __forceinline__ T n2(i64 i) const { return osc * ldh(r2, 2u * off(i), VT{}); }
   __device__ __forceinline__ T q3(i64 i) const { return osc * ldh(r3, 2u * off(i), VT{}); }
   __device__ __forceinline__ T rd(i64, T dv) const { return 1.0f / dv; }
+  // raw fp16 storage words (one per sample of the lane), for the register-cached coefficient rows of the fused POST pass
+  __device__ __forceinline__ unsigned e_raw(i64 i) const { return ldraw(r1, 2u * off(i), VT{}); }
+  __device__ __forceinline__ unsigned n2_raw(i64 i) const { return ldraw(r2, 2u * off(i), VT{}); }
+  __device__ __forceinline__ T cvt(unsigned raw) const { return osc * unraw(raw, VT{}); }
 };
 
 // K_1 x at the NC columns col0 .. col0 + NC - 1 of grid row R, handed column by column to `use(k, K1x, d0, rd)`.
@@ -1254,6 +1271,96 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   VT a0[N1], a1[N1], a2[N1];   // x' rows
   VT b0[N2], b1[N2], b2[N2];   // x3 rows row - 1, row, row + 1
   VT u1[N2], u2[N2];           // bu rows row, row + 1
+  if constexpr (!SHARED && ND == 3) {
+    // Per-sample coefficients (fp32 diagonal + fp16 couplings, one value per lane and sample): every coefficient row is
+    // needed four times -- by the x3 stage and the z stage, as the row's own couplings and as the south couplings of the
+    // row above -- and re-loading it each time missed the caches about half the time (PMC: 4.54 passes of traffic for
+    // 2.6 algorithmic, 5.4 TB/s: bandwidth-bound on wasted re-reads).  Rows are loaded ONCE into a register window, the
+    // couplings kept as raw fp16 words (one VGPR per pair of samples).
+    struct CRow { VT d[N2]; unsigned e[N2 + 1]; unsigned n[N2]; };   // columns c0w - 1 + j; e[j + 1] = east coupling of column j
+    auto load_crow = [&](int R, CRow& c) {
+      const i64 base = (i64)R * W + (c0w - 1);
+      auto at = [&](i64 i) -> i64 { return EDGE ? (i < 0 ? 0 : (i > n - 1 ? n - 1 : i)) : i; };
+      c.e[0] = cf.e_raw(at(base - 1));
+#pragma unroll
+      for (int j = 0; j < N2; ++j) {
+        const i64 i = at(base + j);
+        c.d[j] = cf.d(i);
+        c.e[j + 1] = cf.e_raw(i);
+        c.n[j] = cf.n2_raw(i);
+      }
+    };
+    // K_1 x on NC columns starting at cached column OFF, row couplings c, south couplings sn (the n of the row below)
+    auto k1c = [&](auto nc_tag, auto off_tag, const CRow& c, const unsigned* sn, const VT* xm, const VT* xc, const VT* xq,
+                   auto&& use) {
+      constexpr int NC = decltype(nc_tag)::value, OFF = decltype(off_tag)::value;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int j = k + OFF;
+        const VT d0 = c.d[j];
+        VT acc = d0 * xc[k + 1];
+        acc += cf.cvt(c.e[j + 1]) * xc[k + 2];
+        acc += cf.cvt(c.e[j]) * xc[k];
+        acc += cf.cvt(c.n[j]) * xq[k + 1];
+        acc += cf.cvt(sn[j]) * xm[k + 1];
+        use(k, acc, d0, 1.0f / d0);
+      }
+    };
+    typedef std::integral_constant<int, N2> tN2;
+    typedef std::integral_constant<int, RW> tRW;
+    typedef std::integral_constant<int, 0> t0;
+    typedef std::integral_constant<int, 1> t1;
+    auto x3c = [&](int R, const CRow& c, const unsigned* sn, const VT* am, const VT* ac, const VT* ap, const VT* bu, VT* dst) {
+      if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+        for (int j = 0; j < N2; ++j) dst[j] = Z;
+        return;
+      }
+      k1c(tN2{}, t0{}, c, sn, am, ac, ap, [&](int j, VT kx, VT, VT rd) {
+        const VT v = ac[j + 1] + (wA * rd) * (bu[j] - kx);
+        dst[j] = ok1[j + 1] ? v : Z;
+      });
+    };
+    CRow cS, cC, cN;             // coefficient rows R - 1, R, R + 1 of the x3 row being formed
+    load_crow(r0 - 2, cS);
+    load_crow(r0 - 1, cC);
+    xp_row(r0 - 2, a0);
+    xp_row(r0 - 1, a1);
+    xp_row(r0, a2);
+    bu_row(r0 - 1, u1);
+    x3c(r0 - 1, cC, cS.n, a0, a1, a2, u1, b0);
+#pragma unroll
+    for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+    xp_row(r0 + 1, a2);
+    bu_row(r0, u1);
+    load_crow(r0, cN);
+    x3c(r0, cN, cC.n, a0, a1, a2, u1, b1);
+    // from here on: cS = row - 1 (only its n is used), cC = row, cN = row + 1
+#pragma unroll
+    for (int j = 0; j < N2; ++j) cS.n[j] = cC.n[j];
+    cC = cN;
+    float* __restrict__ pz = zout + ((i64)r0 * W + c0w) * Bp;
+    for (int row = r0; row < r1; ++row) {
+#pragma unroll
+      for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+      xp_row(row + 2, a2);
+      bu_row(row + 1, u2);
+      load_crow(row + 1, cN);
+      x3c(row + 1, cN, cC.n, a0, a1, a2, u2, b2);
+      k1c(tRW{}, t1{}, cC, cS.n, b0, b1, b2, [&](int k, VT kx, VT, VT rd) {
+        if (!EDGE || c0w + k < W) {
+          const VT z = b1[k + 1] + (wB * rd) * (u1[k + 1] - kx);
+          *(VT*)(pz + (i64)k * Bp + lb) = z;
+          if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);
+        }
+      });
+      pz += (i64)W * Bp;
+#pragma unroll
+      for (int j = 0; j < N2; ++j) { b0[j] = b1[j]; b1[j] = b2[j]; u1[j] = u2[j]; cS.n[j] = cC.n[j]; }
+      cC = cN;
+    }
+    return;
+  }
   xp_row(r0 - 2, a0);
   xp_row(r0 - 1, a1);
   xp_row(r0, a2);

@@ -45,6 +45,7 @@ SIGNATURES = {
                                     _P]),
     "diffhe_p1_element_integrals": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "diffhe_ell_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "diffhe_lattice_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_rows_ref": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_atomic": (_I, [_P, _P, _I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_apply_dirichlet": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

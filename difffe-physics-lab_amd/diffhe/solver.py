@@ -279,11 +279,7 @@ class _Engine:
                 # reference's fl(fl(kappa_e t_e) / den_e) per contribution (a cond * eps effect in u, like the factored
                 # form) instead of twelve IEEE fp64 divisions per node and sample (10.3 -> 3 ms at 1024^2 x 256);
                 # operator="assembled" keeps the bit-identical order below
-                _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0ref()), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
-                                                      _hip.ptr(lev.contrib), _hip.ptr(lev.cols),
-                                                      _hip.ptr(lev.store_slot), _hip.ptr(lev.is_bc), _hip.ptr(p.g),
-                                                      _hip.ptr(v), _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
-                           "diffhe_ell_assemble_rows(lattice, per-sample fields)")
+                self._lattice_rows(lev, lev.k0ref(), kl, kse, ksb, p.g, v, lf, Bv, st)
             elif li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
                 _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(lev.tnum), _hip.ptr(lev.den), _hip.ptr(kl), kse, ksb,
                                                           _hip.ptr(lev.ent_ptr), _hip.ptr(lev.contrib),
@@ -291,16 +287,26 @@ class _Engine:
                                                           _hip.ptr(lev.is_bc), _hip.ptr(p.g), _hip.ptr(v), _hip.ptr(lf),
                                                           lev.n, lev.m, 7, Bv, st), "diffhe_ell_assemble_rows_ref(lattice)")
             else:
-                _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
-                                                      _hip.ptr(lev.contrib), _hip.ptr(lev.cols),
-                                                      _hip.ptr(lev.store_slot), _hip.ptr(lev.is_bc),
-                                                      _hip.ptr(p.g if li == 0 else lev.zero_g()), _hip.ptr(v),
-                                                      _hip.ptr(lf), lev.n, lev.m, 7, Bv, st),
-                           "diffhe_ell_assemble_rows(lattice)")
+                self._lattice_rows(lev, lev.k0, kl, kse, ksb, p.g if li == 0 else lev.zero_g(), v, lf, Bv, st)
             vals.append(v)
             if li == 0:
                 lift = lf
         return vals, Bv, scale, lift, scale
+
+    def _lattice_rows(self, lev, local, kl, kse, ksb, g, v, lf, Bv, st):
+        """kappa * k0 gathered into the symmetric diagonals of a lattice level (+ the Dirichlet lift).  The lattice form of
+        the gather (contribution lists written into the kernel, each kappa_e read once per node) gives bitwise the values
+        of the list-driven kernel (tests/test_robustness.py); DIFFHE_LATTICE_ASSEMBLE=0 keeps the latter."""
+        L = self.L
+        if os.environ.get("DIFFHE_LATTICE_ASSEMBLE", "1") != "0":
+            _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(local), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.is_bc),
+                                                      _hip.ptr(g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd, Bv,
+                                                      st), "diffhe_lattice_assemble_rows")
+        else:
+            _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(local), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
+                                                  _hip.ptr(lev.contrib), _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
+                                                  _hip.ptr(lev.is_bc), _hip.ptr(g), _hip.ptr(v), _hip.ptr(lf), lev.n, lev.m,
+                                                  7, Bv, st), "diffhe_ell_assemble_rows(lattice)")
 
     def pack_cycle_coeffs(self, vals, Bv):
         """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, fp16 off-diagonals, scale) per level -- 8 instead of

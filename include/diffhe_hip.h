@@ -132,6 +132,15 @@ int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long
                              const unsigned char* is_bc, const double* g, double* vals, double* lift, int n, int m,
                              int W, int Bv, void* stream);
 
+/* diffhe_ell_assemble_rows for FEMesh.rectangle connectivity (reference mesh.py:100-105) without the gather lists: the
+ * contributions of the seven entry kinds (0, +1, +W, +nx, -1, -W, -nx; the first `nd` stored as symmetric diagonals
+ * (nd, n, Bv), the rest feeding the Dirichlet lift) are written into the kernel in the element order of the
+ * reference's loops (solver.py:137-140) -- bitwise the values of diffhe_ell_assemble_rows with the lattice lists, each
+ * kappa_e read once per node.  local: (9, m) unit element matrices; kappa (optional) strided by kappa_se per element
+ * and kappa_sb per sample. */
+int diffhe_lattice_assemble_rows(const double* local, const double* kappa, long long kappa_se, long long kappa_sb,
+                                 const unsigned char* is_bc, const double* g, double* vals, double* lift, int nx, int ny,
+                                 int nd, int Bv, void* stream);
 /* The same gather assembly in the REFERENCE'S OPERATION ORDER: tnum (npe*npe, m) holds t = b_p b_q + c_p c_q (2D;
  * +-1 in 1D), den (m) holds 4 area (2D; h in 1D), and every contribution is (kappa * t) / den with each operation
  * rounded on its own (no contracted multiply-adds, a true division), added in element order -- solver.py:88-92,

@@ -304,6 +304,48 @@ def test_adjoint_state_is_released_with_the_backward_pass_not_with_the_outputs()
     assert len(S._STATES) == n0 - 1 and u.grad_fn is not None
 
 
+# ---- lattice form of the gather assembly ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh_fn,B", [(lambda: FEMesh.rectangle(37, 29, bc_value=0.3), 64), (lambda: _skewed(40, 33, seed=2), 128),
+                                       (lambda: FEMesh.rectangle(8, 5), 3)])
+def test_lattice_assembly_without_lists_is_bitwise_the_list_driven_gather(mesh_fn, B):
+    """diffhe_lattice_assemble_rows (contribution lists written into the kernel) against diffhe_ell_assemble_rows with
+    the lattice lists: stored diagonals and Dirichlet lift bit for bit, per-sample fields and a shared field, a mesh
+    with interior Dirichlet nodes included."""
+    from diffhe import _hip
+    from diffhe.plan import padded_batch
+    mesh = mesh_fn()
+    d = dict(mesh.dirichlet_nodes)
+    d[mesh.n_nodes // 2 + 3] = -0.7                       # an interior Dirichlet node: lower-triangle lift terms
+    mesh = FEMesh(nodes=mesh.nodes, elements=mesh.elements, dirichlet_nodes=d)
+    plan = get_plan(mesh, torch.device(DEV))
+    assert plan.is_lattice
+    lev = plan.levels[0]
+    L = _hip.lib()
+    Bp = padded_batch(B)
+    g = torch.Generator().manual_seed(3)
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    for Bv, kse, ksb, kap in ((Bp, Bp, 1, (torch.rand(lev.m, Bp, generator=g, dtype=T64) + 0.5).to(DEV)),
+                              (1, 1, 0, (torch.rand(lev.m, 1, generator=g, dtype=T64) + 0.5).to(DEV))):
+        out = []
+        for which in (0, 1):
+            v = torch.full((lev.nd, lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            lf = torch.full((lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            if which == 0:
+                _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kap), kse, ksb, _hip.ptr(lev.ent_ptr),
+                                                      _hip.ptr(lev.contrib), _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
+                                                      _hip.ptr(lev.is_bc), _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.n,
+                                                      lev.m, 7, Bv, st), "lists")
+            else:
+                _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kap), kse, ksb, _hip.ptr(lev.is_bc),
+                                                          _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd,
+                                                          Bv, st), "lattice")
+            torch.cuda.synchronize()
+            out.append((v, lf))
+        assert not torch.isnan(out[1][0]).any() and not torch.isnan(out[1][1]).any()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert float(out[1][1].abs().max()) > 0            # the lift is exercised
+
+
 # ---- node-major entry -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,bc_value", [(64, 0.0), (5, 0.5), (128, 0.5)])
 @pytest.mark.parametrize("per_element", [False, True])
