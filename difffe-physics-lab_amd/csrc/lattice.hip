@@ -1078,6 +1078,152 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
 
   VT a0[N1], a1[N1], a2[N1];   // x1 rows R - 1, R, R + 1 of the x2 row being formed
   VT b0[N2], b1[N2], b2[N2];   // x2 rows row - 1, row, row + 1
+  if constexpr (!SHARED && ND == 3) {
+    // Per-sample coefficients: every coefficient row loaded ONCE into a register window (as in fused_post_body): the
+    // diagonal when the row's x1 is formed (9 columns), its couplings one iteration later for the x2 stage (raw fp16
+    // words), both kept one more iteration for the residual stage; the row below contributes its north couplings.
+    struct CR { VT d[N2]; unsigned e[N2 + 1]; unsigned n[N2]; };   // columns c0w - 1 + j; e[t] = east coupling of column c0w - 2 + t
+    auto at = [&](i64 i) -> i64 { return EDGE ? (i < 0 ? 0 : (i > n - 1 ? n - 1 : i)) : i; };
+    auto load_d = [&](int R, VT* D) {          // diagonal of row R on the N1 columns c0w - 2 + j
+      const i64 base = (i64)R * W + (c0w - 2);
+#pragma unroll
+      for (int j = 0; j < N1; ++j) D[j] = cf.d(at(base + j));
+    };
+    auto load_en = [&](int R, const VT* D, CR& c) {
+      const i64 base = (i64)R * W + (c0w - 2);
+#pragma unroll
+      for (int t = 0; t < N2 + 1; ++t) c.e[t] = cf.e_raw(at(base + t));
+#pragma unroll
+      for (int j = 0; j < N2; ++j) {
+        c.n[j] = cf.n2_raw(at(base + 1 + j));
+        c.d[j] = D[j + 1];
+      }
+    };
+    auto x1c = [&](int R, const VT* D, VT* dst) {
+      if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+        for (int j = 0; j < N1; ++j) dst[j] = Z;
+        return;
+      }
+      const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
+#pragma unroll
+      for (int j = 0; j < N1; ++j) {
+        const VT v = VLane<VT>::ld(rr, off1[j], sx);
+        dst[j] = ok1[j] ? (v * ib) * (w0 * (1.0f / D[j])) : Z;
+      }
+    };
+    auto k1c = [&](auto nc_tag, auto off_tag, const CR& c, const unsigned* sn, const VT* xm, const VT* xc, const VT* xq,
+                   auto&& use) {
+      constexpr int NC = decltype(nc_tag)::value, OFF = decltype(off_tag)::value;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int j = k + OFF;
+        const VT d0 = c.d[j];
+        VT acc = d0 * xc[k + 1];
+        acc += cf.cvt(c.e[j + 1]) * xc[k + 2];
+        acc += cf.cvt(c.e[j]) * xc[k];
+        acc += cf.cvt(c.n[j]) * xq[k + 1];
+        acc += cf.cvt(sn[j]) * xm[k + 1];
+        use(k, acc, d0, 1.0f / d0);
+      }
+    };
+    typedef std::integral_constant<int, N2> tN2;
+    typedef std::integral_constant<int, RW> tRW;
+    typedef std::integral_constant<int, 0> t0;
+    typedef std::integral_constant<int, 1> t1;
+    auto x2c = [&](int R, const CR& c, const unsigned* sn, const VT* am, const VT* ac, const VT* ap, VT* dst) {
+      if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+        for (int j = 0; j < N2; ++j) dst[j] = Z;
+        return;
+      }
+      k1c(tN2{}, t0{}, c, sn, am, ac, ap, [&](int j, VT kx, VT d0, VT rd) {
+        const VT bu = ac[j + 1] * (d0 * inv_w0);
+        const VT v = ac[j + 1] + (w1 * rd) * (bu - kx);
+        dst[j] = ok1[j + 1] ? v : Z;
+      });
+    };
+    VT Dq[N1], Dn[N1];           // diagonals of the newest two x1 rows
+    CR cA, cB;                   // coefficient rows of the x2 row being formed / of the residual row
+    unsigned sS[N2];             // north couplings of the row below the residual row
+    load_d(r0 - 2, Dq);
+    x1c(r0 - 2, Dq, a0);
+    load_en(r0 - 2, Dq, cB);     // only its n is used: south of row r0 - 1
+    load_d(r0 - 1, Dq);
+    x1c(r0 - 1, Dq, a1);
+    load_en(r0 - 1, Dq, cA);
+    load_d(r0, Dn);
+    x1c(r0, Dn, a2);
+    x2c(r0 - 1, cA, cB.n, a0, a1, a2, b0);
+#pragma unroll
+    for (int j = 0; j < N2; ++j) sS[j] = cA.n[j];      // n of row r0 - 1
+#pragma unroll
+    for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+    load_d(r0 + 1, Dq);
+    x1c(r0 + 1, Dq, a2);
+    load_en(r0, Dn, cB);         // coefficient row r0
+    x2c(r0, cB, sS, a0, a1, a2, b1);
+    // loop invariant at the top of iteration `row`: cB = coefficient row `row`, sS = n of row - 1, Dq = diagonal of row + 1
+
+    VT racc[CW], rnext[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) racc[j] = rnext[j] = Z;
+    const int cI0 = (r0 + 1) >> 1, cJ0 = (c0w + 1) >> 1;
+    const int last_store = (r1 >= nyp) ? nyp - 1 : r1 - 2;
+    float* __restrict__ px2 = x2out + ((i64)r0 * W + c0w) * Bp;
+    for (int row = r0; row < r1; ++row) {
+#pragma unroll
+      for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+      load_d(row + 2, Dn);
+      x1c(row + 2, Dn, a2);
+      load_en(row + 1, Dq, cA);
+      x2c(row + 1, cA, cB.n, a0, a1, a2, b2);
+      VT res[RW];
+      k1c(tRW{}, t1{}, cB, sS, b0, b1, b2, [&](int k, VT kx, VT d0, VT) {
+        const VT bu = a0[k + 2] * (d0 * inv_w0);
+        res[k] = (!EDGE || (c0w + k >= 0 && c0w + k < W)) ? bu - kx : Z;
+      });
+      if (row <= last_store) {
+#pragma unroll
+        for (int k = 0; k < RW - 1; ++k) {
+          if (!EDGE || (c0w + k >= 0 && c0w + k < W)) *(VT*)(px2 + (i64)k * Bp + lb) = b1[k + 1];
+        }
+      }
+      px2 += (i64)W * Bp;
+      const bool store = (row & 1) || row + 1 >= nyp;
+      if (!(row & 1)) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) racc[j] += res[2 * j + 1] + 0.5f * (res[2 * j] + res[2 * j + 2]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          racc[j] += 0.5f * (res[2 * j + 1] + res[2 * j]);
+          rnext[j] = 0.5f * (res[2 * j + 1] + res[2 * j + 2]);
+        }
+      }
+      if (store) {
+        const int I = row >> 1;
+        if (I >= cI0) {
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            const int J = cJ0 + j;
+            if (J < cW) {
+              const i64 Ic = (i64)I * cW + J;
+              *(VT*)(crhs + Ic * Bp + lb) = cbc[Ic] ? Z : sb * racc[j];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CW; ++j) { racc[j] = rnext[j]; rnext[j] = Z; }
+      }
+#pragma unroll
+      for (int j = 0; j < N2; ++j) { b0[j] = b1[j]; b1[j] = b2[j]; sS[j] = cB.n[j]; }
+      cB = cA;
+#pragma unroll
+      for (int j = 0; j < N1; ++j) Dq[j] = Dn[j];
+    }
+    return;
+  }
   x1_row(r0 - 2, a0);
   x1_row(r0 - 1, a1);
   x1_row(r0, a2);
@@ -1588,10 +1734,12 @@ inline int env_level_int(const char* name, int level) {
 
 inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
   if (strip2_ok(L, Bv, Bp)) return 3;
-  // per-sample matrices: only the POST pass is fused by default -- the fused PRE pass needs three window rows of x1 AND
-  // per-lane coefficients for three stages (256 VGPRs, one wave per SIMD) and measured slower than its two single passes
-  // (1024^2 x 256 forward solve: 153.1 ms PRE only, 135.5 POST only, 147.9 both, 140.6 neither; gpurun_out/r3y)
-  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 2;
+  // per-sample matrices: both passes fused, with the coefficient rows cached in registers (fp16 couplings as raw words:
+  // 174 / 206 VGPRs, 2 waves per SIMD, no spills).  Without the cache the PRE pass needed 256 VGPRs and measured slower
+  // than its two single passes (forward solve 153 ms against 140), and the POST pass re-read every coefficient row four
+  // times (PMC 4.5 passes of traffic for 2.6 algorithmic); 1024^2 x 256 step: 245 (POST only, uncached) -> 236 (POST
+  // cached) -> 219 ms (both, cached; gpurun_out/r5b, r5d).  DIFFHE_FUSED_PS: bit 0 = PRE, bit 1 = POST.
+  static const int per_sample = getenv("DIFFHE_FUSED_PS") ? atoi(getenv("DIFFHE_FUSED_PS")) : 3;
   return (Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale) ? per_sample : 0;
 }
 

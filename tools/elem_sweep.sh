@@ -10,5 +10,5 @@ v = d["variants"]["kappa_element_field"]
 print(f"{sys.argv[2]:20s} {v['ms_per_step']:8.2f} ms  {v['value_per_gpu']:7.1f} solves/s  its {v['iters_fwd']}+{v['iters_adj']}  all {v['ms_all']}", flush=True)
 PY
 }
-run lat1 X=1
-run lat0 DIFFHE_LATTICE_ASSEMBLE=0
+run ps2 DIFFHE_FUSED_PS=2
+run ps3 DIFFHE_FUSED_PS=3
