@@ -19,7 +19,7 @@ KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "fus
         "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel",
         "cg_spmv_kernel", "ell_jacobi_kernel", "ell_galerkin_kernel", "ell_residual_out_kernel", "agg_restrict_kernel",
         "sa_prolong_add_kernel", "amg_update_kernel", "assemble_rows_kernel", "lattice_grad_kappa_kernel",
-        "grad_kappa_shared_kernel")
+        "grad_kappa_shared_kernel", "lattice_assemble_kernel")
 
 
 def short(name):
