@@ -7,11 +7,10 @@ run() {  # label, env...
 import json, sys
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
-o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in r["other_kernels"]}
-print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  update {r['avg_launch_ms']}  others {o}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
+print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run base X=1
-run pv6 DIFFHE_PUPD_VARIANT=6
-run pv8 DIFFHE_PUPD_VARIANT=8
-run base2 X=1
+run sb6144 X=1
+run sb8192 DIFFHE_STRIP_BLOCKS=8192
+run sb4096 DIFFHE_STRIP_BLOCKS=4096
+run sb3072 DIFFHE_STRIP_BLOCKS=3072
