@@ -2538,13 +2538,24 @@ int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
   g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
   const int gy = H.Bp / (spl * kWave);
   int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
-  if (nrc > (C.ny + 1) / 4) nrc = (C.ny + 1) / 4;
+  // Levels of <= 300 columns cannot fill the GPU with 4-coarse-row tiles: shorter tiles (2 coarse rows going down, ~5 fine
+  // rows going up) double the independent marches; -1.4 ms per 1024^2 step, neutral on the 513^2 level (gpurun_out/r5j, r5k)
+  const bool small = L.W <= 300;
+  const int cap = small ? (C.ny + 1) / 2 : (C.ny + 1) / 4;
+  if (nrc > cap) nrc = cap;
   if (nrc < 1) nrc = 1;
   g.TR = (C.ny + 1 + nrc - 1) / nrc;  // coarse rows per tile
   if (const int tr = env_level_int("DIFFHE_FUSED_TR_PRE", l)) g.TR = tr;
   g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
   *gpre = g;
   *gpost = strip_geom(L, H.Bp, 4, spl);
+  if (small) {
+    const int nyp = L.ny + 1;
+    int tr = 4;
+    while (gpost->ncb * ((nyp + tr - 1) / tr) > kPartBlocks) ++tr;
+    gpost->TR = tr;
+    gpost->nrc = (nyp + tr - 1) / tr;
+  }
   if (const int tr = env_level_int("DIFFHE_FUSED_TR_POST", l)) {
     if (gpost->ncb * ((L.ny + 1 + tr - 1) / tr) <= kPartBlocks) {
       gpost->TR = tr;
