@@ -2422,6 +2422,68 @@ __global__ __launch_bounds__(256) void mg_dense_solve_kernel(int n, const TV* __
   }
 }
 
+// The same product on the matrix cores (fp32 storage only): X (n x Bp) = inv (n x n) . R (n x Bp) is a plain GEMM, the one
+// GEMM-shaped piece of the path.  v_mfma_f32_32x32x2_f32: a block owns 32 rows x 32 samples, its 4 waves split the sum
+// over j and meet in LDS.  A-operand: lane l supplies inv[i0 + l % 32][j + l / 32] -- read as inv[j + l / 32][i0 + l % 32]
+// (the inverse of a symmetric matrix is symmetric), so the 32 lanes of a half-wave read 128 contiguous bytes;
+// B-operand: rhs[j + l / 32][b0 + l % 32], contiguous as well.  Accumulates in fp32 where the scalar kernel above
+// accumulates in fp64: inside an fp32-stored preconditioner the 1e-6 this costs on the coarsest-level solve is immaterial
+// (same iteration counts, tests/test_robustness.py).  D layout: lane l holds column l % 32, rows 8 (v / 4) + 4 (l / 32) + v % 4.
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mg_dense_mfma_kernel(int n, const float* __restrict__ inv,
+                                                             const double* __restrict__ scale,
+                                                             const float* __restrict__ rhs, float* __restrict__ x, int Bp) {
+  __shared__ float red[3][16][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int il = lane & 31, kh = lane >> 5;
+  const int i0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int ia = (i0 + il < n) ? i0 + il : n - 1;
+  const float* __restrict__ pa = inv + ia;
+  const float* __restrict__ pb = rhs + b0 + il;
+  const int nkp = (n + 1) >> 1, q = (nkp + 3) >> 2;
+  const int kp0 = wave * q, kp1 = (kp0 + q < nkp) ? kp0 + q : nkp;
+  f16v acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  int kp = kp0;
+  for (; kp + 4 <= kp1; kp += 4) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = 2 * (kp + u) + kh;
+      const bool ok = j < n;
+      const int jj = ok ? j : 0;
+      a[u] = ok ? pa[(i64)jj * n] : 0.0f;
+      b[u] = ok ? pb[(i64)jj * Bp] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; kp < kp1; ++kp) {
+    const int j = 2 * kp + kh;
+    const bool ok = j < n;
+    const int jj = ok ? j : 0;
+    const float a = ok ? pa[(i64)jj * n] : 0.0f;
+    const float b = ok ? pb[(i64)jj * Bp] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[wave - 1][v][lane] = acc[v];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float si = scale ? (float)(1.0 / scale[b0 + il]) : 1.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = i0 + 8 * (v >> 2) + 4 * kh + (v & 3);
+      const float t = (acc[v] + red[0][v][lane]) + (red[1][v][lane] + red[2][v][lane]);
+      if (i < n) x[(i64)i * Bp + b0 + il] = si * t;
+    }
+  }
+}
+
 // The same product for batches below a wave (Bp = 1 .. 32, the unbatched call shape of the reference): one wave per
 // row, lanes over the columns j, a wave reduction per sample.
 template <typename TV>
@@ -2454,7 +2516,12 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   const Level& L = H.lev[l];
   if (L.inv && H.Bv == 1 && L.n <= kPartBlocks) {  // dense inverse of the shared level matrix: one launch
     diffhe::account(2.0 * sizeof(TV) * (double)L.n * H.Bp);
-    if (H.Bp >= kWave) {
+    static const int use_mfma = getenv("DIFFHE_DENSE_MFMA") ? atoi(getenv("DIFFHE_DENSE_MFMA")) : 1;
+    if (use_mfma && sizeof(TV) == 4 && H.Bp >= kWave && !part) {
+      hipLaunchKernelGGL(mg_dense_mfma_kernel, dim3((L.n + 31) / 32, H.Bp / 32), dim3(256), 0, st, L.n, (const float*)L.inv,
+                         H.scale, (const float*)rhs, (float*)H.xa[l], H.Bp);
+      if (nblocks) *nblocks = 0;
+    } else if (H.Bp >= kWave) {
       constexpr int RPB = 4;
       const dim3 grid((L.n + RPB - 1) / RPB, H.Bp / kWave);
       hipLaunchKernelGGL((mg_dense_solve_kernel<TV, RPB>), grid, dim3(256), 0, st, L.n, (const TV*)L.inv, H.scale, rhs,

@@ -10,7 +10,7 @@ r = d["roofline"]
 print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run new X=1
-run c44_22 DIFFHE_FUSED_TR_POST=0:0:4:4 DIFFHE_FUSED_TR_PRE=0:0:2:2
-run old DIFFHE_FUSED_TR_POST=0:0:9:9 DIFFHE_FUSED_TR_PRE=0:0:4:4
-run new2 X=1
+run mfma1 X=1
+run mfma0 DIFFHE_DENSE_MFMA=0
+run mfma1b X=1
+run mfma0b DIFFHE_DENSE_MFMA=0
