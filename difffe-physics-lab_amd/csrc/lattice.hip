@@ -2430,10 +2430,11 @@ __global__ __launch_bounds__(256) void mg_dense_solve_kernel(int n, const TV* __
 // accumulates in fp64: inside an fp32-stored preconditioner the 1e-6 this costs on the coarsest-level solve is immaterial
 // (same iteration counts, tests/test_robustness.py).  D layout: lane l holds column l % 32, rows 8 (v / 4) + 4 (l / 32) + v % 4.
 typedef float f16v __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void mg_dense_mfma_kernel(int n, const float* __restrict__ inv,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mg_dense_mfma_kernel(int n, const float* __restrict__ inv,
                                                              const double* __restrict__ scale,
                                                              const float* __restrict__ rhs, float* __restrict__ x, int Bp) {
-  __shared__ float red[3][16][kWave];
+  __shared__ float red[NW - 1][16][kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int il = lane & 31, kh = lane >> 5;
@@ -2441,7 +2442,7 @@ __global__ __launch_bounds__(256) void mg_dense_mfma_kernel(int n, const float* 
   const int ia = (i0 + il < n) ? i0 + il : n - 1;
   const float* __restrict__ pa = inv + ia;
   const float* __restrict__ pb = rhs + b0 + il;
-  const int nkp = (n + 1) >> 1, q = (nkp + 3) >> 2;
+  const int nkp = (n + 1) >> 1, q = (nkp + NW - 1) / NW;
   const int kp0 = wave * q, kp1 = (kp0 + q < nkp) ? kp0 + q : nkp;
   f16v acc;
 #pragma unroll
@@ -2478,7 +2479,9 @@ __global__ __launch_bounds__(256) void mg_dense_mfma_kernel(int n, const float* 
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int i = i0 + 8 * (v >> 2) + 4 * kh + (v & 3);
-      const float t = (acc[v] + red[0][v][lane]) + (red[1][v][lane] + red[2][v][lane]);
+      float t = acc[v];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) t += red[w][v][lane];
       if (i < n) x[(i64)i * Bp + b0 + il] = si * t;
     }
   }
@@ -2518,8 +2521,14 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
     diffhe::account(2.0 * sizeof(TV) * (double)L.n * H.Bp);
     static const int use_mfma = getenv("DIFFHE_DENSE_MFMA") ? atoi(getenv("DIFFHE_DENSE_MFMA")) : 1;
     if (use_mfma && sizeof(TV) == 4 && H.Bp >= kWave && !part) {
-      hipLaunchKernelGGL(mg_dense_mfma_kernel, dim3((L.n + 31) / 32, H.Bp / 32), dim3(256), 0, st, L.n, (const float*)L.inv,
-                         H.scale, (const float*)rhs, (float*)H.xa[l], H.Bp);
+      // 8 waves per 32 x 32 tile split the sum over j: 1089 nodes x 256 samples = 280 blocks, a chain of 17 dependent
+      // 4-step groups per wave (4 waves: 28 us, the scalar fp64-accumulating kernel: 51 us)
+      if (use_mfma == 4)
+        hipLaunchKernelGGL(mg_dense_mfma_kernel<4>, dim3((L.n + 31) / 32, H.Bp / 32), dim3(256), 0, st, L.n, (const float*)L.inv,
+                           H.scale, (const float*)rhs, (float*)H.xa[l], H.Bp);
+      else
+        hipLaunchKernelGGL(mg_dense_mfma_kernel<8>, dim3((L.n + 31) / 32, H.Bp / 32), dim3(512), 0, st, L.n, (const float*)L.inv,
+                           H.scale, (const float*)rhs, (float*)H.xa[l], H.Bp);
       if (nblocks) *nblocks = 0;
     } else if (H.Bp >= kWave) {
       constexpr int RPB = 4;

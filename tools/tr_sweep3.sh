@@ -10,7 +10,7 @@ r = d["roofline"]
 print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f}  iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run mfma1 X=1
-run mfma0 DIFFHE_DENSE_MFMA=0
-run mfma1b X=1
-run mfma0b DIFFHE_DENSE_MFMA=0
+run mfma8 X=1
+run mfma4 DIFFHE_DENSE_MFMA=4
+run mfma8b X=1
+run mfma4b DIFFHE_DENSE_MFMA=4
