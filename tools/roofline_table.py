@@ -37,6 +37,7 @@ RULES = [
     ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),
     ("pcg_finish_kernel", "x += sum_j alpha_j p_j + V(r) (end of a solve; 5 directions)", 5.0),
     ("mg_dense_solve_kernel", "dense coarse solve (33^2 level)", 0.0),
+    ("mg_dense_mfma_kernel", "dense coarse solve (33^2 level) on MFMA", 0.0),
     ("pcg_init_kernel", "b.b and fp32 copy of b (x, r are set after the full-multigrid start)", 1.5),
     ("to_node_major_kernel", "(B,n) -> (n,Bp)", 2.0),
     ("to_sample_major_kernel", "(n,Bp) -> (B,n)", 2.0),
@@ -71,7 +72,11 @@ def main(path):
                 gbs = passes * PASS / (avg * 1e-9) / 1e9
                 share = sum(durs) / total
                 seen += sum(durs)
-                print(f"| `{label}` | {len(fine)} | {avg / 1e6:.3f} | {gbs:.0f} | {gbs / 8000:.2f} | {100 * share:.1f} % (all levels) |")
+                if gbs > 8000 and passes > 0 and "b.b" not in label:
+                    # faster than the HBM peak at fine-level bytes: this instantiation only ever ran on coarser levels
+                    print(f"| `{label}` -- coarser levels only in this run ({name[:60]}) | {len(durs)} | {avg / 1e6:.3f} (largest level) | | | {100 * share:.1f} % |")
+                else:
+                    print(f"| `{label}` | {len(fine)} | {avg / 1e6:.3f} | {gbs:.0f} | {gbs / 8000:.2f} | {100 * share:.1f} % (all levels) |")
     print(f"| everything else (coarse-level simple kernels, scalars, torch ops) | | | | | {100 * (total - seen) / total:.1f} % |")
 
 
