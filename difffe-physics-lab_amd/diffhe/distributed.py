@@ -109,14 +109,23 @@ def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None, collective=
                 if stats is not None:
                     stats["staged_bytes"] += buf.numel() * buf.element_size()
             mine = torch.empty(buf.numel() // world, dtype=buf.dtype, device=buf.device)
-            coll.reduce_scatter(mine, buf)                     # this rank's 1/world of the sum
-            coll.all_gather(buf, mine)                         # ... handed to everyone
+            try:
+                coll.reduce_scatter(mine, buf)                 # this rank's 1/world of the sum
+                two_phase = True
+            except (RuntimeError, NotImplementedError, AttributeError) as exc:
+                # a backend / build without reduce_scatter_tensor: `buf` is untouched (the result went to `mine`), so
+                # the plain all-reduce is still exact.  Every rank raises alike (same call, same arguments).
+                coll.all_reduce(buf)
+                two_phase = False
+                paths.append(f"all_reduce(fallback: {type(exc).__name__})")
+            if two_phase:
+                coll.all_gather(buf, mine)                     # ... handed to everyone
+                paths.append("reduce_scatter+all_gather" + ("" if direct else "(staged)"))
             if not direct:
                 t.copy_(buf[:n].reshape(t.shape))
-            paths.append("reduce_scatter+all_gather" + ("" if direct else "(staged)"))
             if stats is not None:
                 stats["bytes"] += n * t.element_size()
-                stats["collectives"] += 2
+                stats["collectives"] += 2 if two_phase else 1
     if stats is not None:
         stats["path"] = " | ".join(paths)
 
