@@ -480,7 +480,7 @@ KERNEL_NAMES_FUSED = [KERNEL_NAMES[0], KERNEL_NAMES[1],
                       KERNEL_NAMES[5]]
 
 
-def kernel_table(kprof, n, Bp, f32, fused=False, rupd=0):
+def kernel_table(kprof, n, Bp, f32, fused=False, rupd=False):
     """Per-kernel roofline rows from the in-solver HIP-event totals (fine level, forward solves)."""
     tv = 4.0 if f32 else 8.0
     bytes_ = [(3 * tv + 8.0), 24.0 + (4.0 if f32 else 0.0), 2.0 * tv, 2.25 * tv, 3.25 * tv, 3.0 * tv]
@@ -488,8 +488,8 @@ def kernel_table(kprof, n, Bp, f32, fused=False, rupd=0):
     if fused and f32:
         bytes_[2], bytes_[4], names = 9.0, 13.0, list(KERNEL_NAMES_FUSED)
     if rupd and f32:   # A p never stored: CG step z, p_old in, p out; residual update p, r in, r and its fp32 copy out
-        bytes_[0], bytes_[1] = 12.0, (20.0 if rupd == 2 else 24.0)     # 2: residual as an fp32 pair, no fp64 copy
-        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, (KERNEL_NAME_RUPD_PAIR if rupd == 2 else KERNEL_NAME_RUPD)
+        bytes_[0], bytes_[1] = 12.0, 24.0
+        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, KERNEL_NAME_RUPD
     rows = []
     for nm, bpn, (ms_, n_) in zip(names, bytes_, kprof):
         if n_ > 0:
@@ -566,7 +566,7 @@ def variant_config2(args, torch, L, _hip, ctypes, dev, timed):
 
 def _lattice_variant_roofline(L, ctypes, n, Bp, f32):
     rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0,
-                        rupd=int(L.diffhe_lattice_recompute_ap()) if f32 else 0)
+                        rupd=bool(L.diffhe_lattice_recompute_ap()) and f32)
     if not rows:
         return None
     top = dict(rows[0])
@@ -713,8 +713,6 @@ KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, f
 
 KERNEL_NAME_CGSTEP_NOAP = "fused CG step: p = z + beta p stored, p.Ap with A p kept in registers (never stored; 12 B)"
 KERNEL_NAME_RUPD = "residual update with A p recomputed from the stored p: r -= alpha A p, r.r, fp32 copy of r (24 B)"
-KERNEL_NAME_RUPD_PAIR = ("residual update with A p recomputed from the stored p, residual kept as an fp32 pair (r32, r_lo): "
-                         "r -= alpha A p, r.r (20 B)")
 KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, false, 4, 5>"
 
 
@@ -732,7 +730,7 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
         return None
     f32 = bool(solver.mg.get("fp32"))
     fused = bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0 and bool(solver.mg.get("fused", 1))
-    rupd = int(L.diffhe_lattice_recompute_ap()) if f32 else 0
+    rupd = bool(L.diffhe_lattice_recompute_ap()) and f32
     table = kernel_table(kprof, n, Bp, f32, fused, rupd)
     if not table:
         return None
@@ -743,7 +741,7 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     traffic, src = pmc_traffic(have, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")
     names = list(KERNEL_NAMES_FUSED if fused else KERNEL_NAMES)
     if rupd:
-        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, (KERNEL_NAME_RUPD_PAIR if rupd == 2 else KERNEL_NAME_RUPD)
+        names[0], names[1] = KERNEL_NAME_CGSTEP_NOAP, KERNEL_NAME_RUPD
     by_name = dict(zip(names, symbols))
     for row in table:
         row["symbol"] = by_name[row["kernel"]] if f32 else None

@@ -215,8 +215,6 @@ struct Extra {
   const unsigned char* mask;  // M_APPLY, F_NONE: rows with mask[i] != 0 are stored as 0 (may be NULL)
   int dot_bx;               // M_RESID, F_NONE: the partial sums hold b.x (energy of the iterate) instead of r.r ...
   double* part2;            //   ... and these (same layout as `part`) x.(A x)
-  float* r_lo;              // with r32: the residual is kept as the PAIR (r32, r_lo), rscale * r = r32 + r_lo (48 bits), no fp64
-                            //   copy -- M_RESID writes the pair, F_RUPD reads and writes it (NULL: fp64 r + fp32 copy)
 };
 
 template <typename TV, typename TA, typename TM, int MODE, int FUSE, int ND, bool SHARED, bool XFROMB, int RW,
@@ -274,12 +272,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   // F_PUPD row pointers at (row, c0w), advanced with the others
   const TA* __restrict__ pz = (is_pupd(FUSE)) ? aux + i0 * Bp : nullptr;
   const TA* __restrict__ ppi = (is_pupd(FUSE) || FUSE == F_RUPD) ? (const TA*)ex.p_in + i0 * Bp : nullptr;
-  double* __restrict__ pr = (FUSE == F_RUPD && ex.x) ? ex.x + i0 * Bp : nullptr;  // F_RUPD: ex.x is the residual r (fp64 form)
+  double* __restrict__ pr = (FUSE == F_RUPD) ? ex.x + i0 * Bp : nullptr;          // F_RUPD: ex.x is the residual r
   float* __restrict__ pr32 = (FUSE == F_RUPD && ex.r32) ? ex.r32 + i0 * Bp : nullptr;
-  float* __restrict__ prlo = (FUSE == F_RUPD && ex.r_lo) ? ex.r_lo + i0 * Bp : nullptr;
   const double alpha_cur = (FUSE == F_RUPD) ? ex.alpha[b] : 0.0;
   const double rsc_u = (FUSE == F_RUPD && ex.r32 && ex.rscale) ? ex.rscale[b] : 1.0;
-  const double inv_rsc_u = 1.0 / rsc_u;      // rscale is a power of two: exact
   TA* __restrict__ ppo = (is_pupd(FUSE)) ? (TA*)ex.p_out + i0 * Bp : nullptr;
   double* __restrict__ pxx = (FUSE == F_PUPD && ex.x) ? ex.x + i0 * Bp : nullptr;  // NULL: the iterate is not touched
 
@@ -384,21 +380,10 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
       const double diag = SHIFT ? sb * d0[k] + sh : sb * d0[k];
       const double Ax = SHIFT ? sb * acc + sh * xc[q] : sb * acc;
       if (MODE == M_APPLY && FUSE == F_RUPD) {
-        double ri;
-        if (prlo) {   // residual kept as an fp32 pair: the high part IS the V-cycle's right-hand side
-          float* rh = &(pr32 + o)[lb];
-          float* rl = &(prlo + o)[lb];
-          ri = ((double)*rh + (double)*rl) * inv_rsc_u - alpha_cur * Ax;
-          const double sc = ri * rsc_u;
-          const float h = (float)sc;
-          *rh = h;
-          *rl = (float)(sc - (double)h);
-        } else {
-          double* ra = &(pr + o)[lb];
-          ri = __builtin_nontemporal_load(ra) - alpha_cur * Ax;
-          __builtin_nontemporal_store(ri, ra);
-          if (pr32) (pr32 + o)[lb] = (float)(ri * rsc_u);   // read again right away by the V-cycle: left cacheable
-        }
+        double* ra = &(pr + o)[lb];
+        const double ri = __builtin_nontemporal_load(ra) - alpha_cur * Ax;
+        __builtin_nontemporal_store(ri, ra);
+        if (pr32) (pr32 + o)[lb] = (float)(ri * rsc_u);   // read again right away by the V-cycle: left cacheable
         s += ri * ri;
       } else if (MODE == M_APPLY) {
         double y = Ax;
@@ -435,13 +420,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
           resrow[k] = res;
         } else if (MODE == M_RESID) {
           if (po) (po + o)[lb] = (TV)res;
-          if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) {
-            const i64 og = ((i64)row * W + c0w + k) * Bp;
-            const double sc = res * rsc;
-            const float h = (float)sc;
-            (ex.r32 + og)[lb] = h;
-            if (ex.r_lo) (ex.r_lo + og)[lb] = (float)(sc - (double)h);
-          }
+          if (FUSE == F_NONE && sizeof(TV) == 8 && ex.r32) (ex.r32 + ((i64)row * W + c0w + k) * Bp)[lb] = (float)(res * rsc);
           if (FUSE == F_NONE && ex.dot_bx) {
             s += bi * xc[q];
             s2 += xc[q] * (bi - res);   // x.(A x)
@@ -503,7 +482,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     if (pb) pb += rowX;
     if (po) po += rowX;
     if (is_pupd(FUSE)) { pz += rowX; ppi += rowX; ppo += rowX; if (FUSE == F_PUPD && pxx) pxx += rowX; }
-    if (FUSE == F_RUPD) { ppi += rowX; if (pr) pr += rowX; if (pr32) pr32 += rowX; if (prlo) prlo += rowX; }
+    if (FUSE == F_RUPD) { ppi += rowX; pr += rowX; if (pr32) pr32 += rowX; }
   }
   return s;
 }
@@ -1647,9 +1626,9 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
     const double tv = sizeof(TV), ta = sizeof(TA);
     double bpn;
     if (MODE == M_JACOBI) bpn = (XFROMB ? 2.0 : 3.0) * tv + (FUSE == F_PROLONG ? 0.25 * tv : 0.0);
-    else if (MODE == M_RESID) bpn = 2.0 * tv + (FUSE == F_RESTRICT ? 0.25 * tv : (out ? tv : 0.0) + (ex.r32 ? 4.0 : 0.0) + (ex.r_lo ? 4.0 : 0.0));
+    else if (MODE == M_RESID) bpn = 2.0 * tv + (FUSE == F_RESTRICT ? 0.25 * tv : (out ? tv : 0.0) + (ex.r32 ? 4.0 : 0.0));
     else if (is_pupd(FUSE)) bpn = (ex.first ? 2.0 * ta : 3.0 * ta) + (out ? 8.0 : 0.0) + ((FUSE == F_PUPD && ex.x) ? 16.0 : 0.0);
-    else if (FUSE == F_RUPD) bpn = ta + 16.0 + ((ex.r32 && !ex.r_lo) ? 4.0 : 0.0);
+    else if (FUSE == F_RUPD) bpn = ta + 16.0 + (ex.r32 ? 4.0 : 0.0);
     else bpn = tv + (out ? tv : 0.0) + (ex.dotv ? 8.0 : 0.0);
     if (Bv != 1) bpn += m16 ? 4.0 + 2.0 * (L.nd - 1) : L.nd * (m32 ? 4.0 : 8.0);
     diffhe::account(bpn * (double)L.n * Bp);
@@ -2045,16 +2024,12 @@ __global__ __launch_bounds__(256) void dia_maxdiag_kernel(Level L, int Bv, unsig
 // power of two rs ~ 1 / |b| (S_INIT), so they stay inside the fp32 range whatever the magnitude of the data
 // (forcing of amplitude 1e-35 used to underflow them); powers of two make the scaling exact, so nothing else changes.
 __global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__ r, const double* __restrict__ rs,
-                                                       float* __restrict__ r32, int n, int Bp,
-                                                       float* __restrict__ r_lo = nullptr) {
+                                                       float* __restrict__ r32, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   const double sc = rs ? rs[nm.b] : 1.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
-    const double v = r[o] * sc;
-    const float h = (float)v;
-    r32[o] = h;
-    if (r_lo) r_lo[o] = (float)(v - (double)h);   // pair form of the residual (Extra::r_lo)
+    r32[o] = (float)(r[o] * sc);
   }
 }
 
@@ -3055,28 +3030,23 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     return DIFFHE_OK;
   }
 
+  int nbz = 0, nba = 0;
+  const bool light_init = (use_fmg && f32) || warm;  // the start overwrites x and r (cold) / x is the caller's guess (warm)
+  LAUNCH(light_init ? 8.0 : 24.0, pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
+  SCALAR(S_INIT, partA, nblk);
+  if (f32 && !warm) LAUNCH(12.0, pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp);  // fp32 copy of rs * b (rs from S_INIT)
+  // Fused loop (fine level runs the strip kernels): per iteration
+  //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
+  //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
+  // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
+  // development knob: strip width / occupancy of the fused CG step (gpurun_out/r2l/variants.txt)
   static const int pupd_variant = getenv("DIFFHE_PUPD_VARIANT") ? atoi(getenv("DIFFHE_PUPD_VARIANT")) : 0;
   const StripGeom g0 = strip_geom(L0, Bp, kPupdCols);
   const bool fused = g0.use;
   // batch-shared matrix, fp32-stored directions: A p is never stored -- the residual update recomputes it from p (F_RUPD)
   const int rupd_mode = rupd_env();
   const bool rupd = fused && f32 && Bv == 1 && rupd_mode != 0;
-  // with it the residual lives as an fp32 PAIR (r32, r_lo): rs r = r32 + r_lo to 48 bits, r32 being the V-cycle's
-  // right-hand side anyway -- the fp64 residual and its separate copy (8 + 4 B read / written per update) become 4 + 4
-  const bool rsplit = rupd && diffhe_lattice_recompute_ap() == 2;
-  float* const rlo = rsplit ? (float*)r : nullptr;     // the fp64 residual's buffer is free in that form
   const StripGeom g8 = strip_geom(L0, Bp, 8);
-  int nbz = 0, nba = 0;
-  const bool light_init = (use_fmg && f32) || warm;  // the start overwrites x and r (cold) / x is the caller's guess (warm)
-  LAUNCH(light_init ? 8.0 : 24.0, pcg_init_kernel, n, b, light_init ? (double*)nullptr : x, r, partA, n, Bp);
-  SCALAR(S_INIT, partA, nblk);
-  // fp32 copy of rs * b (rs from S_INIT); pair form without a full-multigrid start: the residual starts as b
-  if (f32 && !warm) LAUNCH(12.0, pcg_cvt_kernel, n, b, (const double*)S.rs, r32, n, Bp, (rsplit && !use_fmg) ? rlo : (float*)nullptr);
-  // Fused loop (fine level runs the strip kernels): per iteration
-  //   [p = z + beta p ; x += alpha_prev p_old ; Ap = A p ; p.Ap]  ->  alpha  ->  [r -= alpha Ap ; r.r]
-  //   -> convergence flags  ->  z = V(r) (last sweep leaves r.z)  ->  beta
-  // Unfused fallback (small meshes / batches): separate p-update, apply and x/r update kernels.
-  // development knob: strip width / occupancy of the fused CG step (gpurun_out/r2l/variants.txt)
   const void* z = nullptr;
   int it = 0, flushed = 0;       // iterations done / directions already folded into x (fused loop)
   // x += sum_{j = flushed .. it-1} alpha_j p_j  (+ z / rs at the end of the solve: pcg_finish_kernel)
@@ -3143,11 +3113,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       Extra ex{};
       ex.r32 = r32;
       ex.rscale = S.rs;
-      ex.r_lo = rlo;
       ex.dot_bx = energy ? 1 : 0;   // partial sums of this pass: b.x0 and x0.(A x0) (S_ENERGY / S_ENERGY2)
       ex.part2 = energy ? partB : nullptr;
-      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, rsplit ? (double*)nullptr : r, 0.0, 0.0,
-                                           energy ? partA : (double*)nullptr, Bp, gr, st, ex);
+      launch_strip<double, M_RESID, false>(L0, Bv, scale, (const double*)x, b, r, 0.0, 0.0, energy ? partA : (double*)nullptr,
+                                           Bp, gr, st, ex);
       nba = gr.ncb * gr.nrc;
     } else {
       nba = op_residual<double>(H, 0, b, (const double*)x, r, energy ? partA : (double*)nullptr, st, energy ? 1 : 0,
@@ -3195,9 +3164,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     if (rupd) {
       Extra ex{};
       ex.p_in = (char*)p + (size_t)(it % n_slots) * slot_stride * sizeof(float);   // the direction apply_step just stored
-      ex.x = rsplit ? (double*)nullptr : r;
+      ex.x = r;
       ex.r32 = r32;
-      ex.r_lo = rlo;
       ex.rscale = S.rs;
       ex.alpha = S.alpha;
 #define RUV(RW_, MINW_, G_)                                                                                            \
@@ -3239,11 +3207,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   return DIFFHE_OK;
 }
 
-extern "C" int diffhe_lattice_recompute_ap(void) {
-  if (rupd_env() == 0) return 0;
-  const int split = getenv("DIFFHE_RSPLIT") ? atoi(getenv("DIFFHE_RSPLIT")) : 1;
-  return split ? 2 : 1;
-}
+extern "C" int diffhe_lattice_recompute_ap(void) { return rupd_env() != 0; }
 
 extern "C" int diffhe_lattice_blocks(int n, int Bp) { (void)n; (void)Bp; return kPartBlocks; }
 

@@ -331,10 +331,8 @@ int diffhe_lattice_blocks(int n, int Bp);
 int diffhe_lattice_fused_passes(void);
 /* 1: with a batch-shared matrix and fp32-stored search directions the PCG never stores A p -- the fused CG step keeps it
  * in registers for p.Ap (12 B per node and sample: z, p_old read, p written) and the residual update recomputes it from
- * the stored p (24 B: p, r read; r and its fp32 copy written; kernel-profile id 1).  2 (the default): in addition the
- * residual is kept as an fp32 PAIR (r32, r_lo), rs r = r32 + r_lo to 48 bits, whose high part is the V-cycle's
- * right-hand side: the update moves 20 B (p, pair read; pair written), no fp64 residual exists (DIFFHE_RSPLIT=0: 1).
- * 0 (environment DIFFHE_RUPD=0): A p is written by the CG step (20 B) and read back by pcg_update_kernel (28 B). */
+ * the stored p (24 B: p, r read; r and its fp32 copy written; kernel-profile id 1).  0 (environment DIFFHE_RUPD=0): A p
+ * is written by the CG step (20 B) and read back by pcg_update_kernel (28 B). */
 int diffhe_lattice_recompute_ap(void);
 int diffhe_lattice_apply(const diffhe_mg_level* level, int Bv, const double* scale, const double* x, double* y,
                          double* part, int Bp, void* stream);

@@ -15,7 +15,7 @@ PASS = 8.0 * N * BP
 # (substring of the kernel name, template-argument pattern) -> (label, algorithmic passes per launch)
 RULES = [
     ("dia_strip_kernel<double, float, double, 0, 4", "fused CG step (p = z + beta p stored, p.Ap; A p kept in registers, x formed at the end), z/p fp32", 1.5),
-    ("dia_strip_kernel<double, float, double, 0, 5", "residual update, A p recomputed from p, residual as an fp32 pair: r -= alpha A p, r.r", 2.5),
+    ("dia_strip_kernel<double, float, double, 0, 5", "residual update, A p recomputed from p: r -= alpha A p, r.r, fp32 copy of r", 3.0),
     ("dia_strip_kernel<double, double, double, 0, 4", "fused CG step, z/p fp64", 4.0),
     ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step with the x update (isolated launches of bench.py only)", 4.5),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
@@ -31,7 +31,7 @@ RULES = [
     ("dia_strip_kernel<float, float, double, 2, 0, 3, true, false", "Jacobi sweep (fp32)", 1.5),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, true", "first two Jacobi sweeps from 0 (fp64)", 2.0),
     ("dia_strip_kernel<double, double, double, 1, 3", "residual + restriction (fp64)", 2.25),
-    ("dia_strip_kernel<double, double, double, 1, 0", "residual (fp64 arithmetic; written as an fp32 pair after the start, not written at the end)", 3.0),
+    ("dia_strip_kernel<double, double, double, 1, 0", "residual (fp64)", 3.0),
     ("dia_strip_kernel<double, double, double, 2, 1", "prolong + correct + Jacobi sweep (fp64)", 3.25),
     ("dia_strip_kernel<double, double, double, 2, 0, 3, true, false", "Jacobi sweep (fp64)", 3.0),
     ("pcg_axpy_kernel", "x += alpha p (flush)", 2.5),

@@ -11,7 +11,8 @@ o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in r["other_kernels"]}
 print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f} pre {o.get('fused_pre_kernel')} iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
-run split1 X=1
-run split0 DIFFHE_RSPLIT=0
-run split1b X=1
-run split0b DIFFHE_RSPLIT=0
+run cw2 X=1
+run cw1 DIFFHE_PRE_CW=1
+run cw1_tr8 DIFFHE_PRE_CW=1 DIFFHE_FUSED_TR_PRE=8
+run cw1_tr16 DIFFHE_PRE_CW=1 DIFFHE_FUSED_TR_PRE=16
+run cw2b X=1
