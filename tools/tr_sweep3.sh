@@ -8,7 +8,7 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
 o = {k["symbol"].split("<")[0]: k["avg_launch_ms"] for k in r["other_kernels"]}
-print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f} pre {o.get('fused_pre_kernel')} iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
+print(f"{sys.argv[2]:20s} step {d['ms_per_step']:8.3f} ms  median {d['timed_steps_ms']['median']:8.3f} upd {r['avg_launch_ms'] if 'update' in r['kernel'] else [k['avg_launch_ms'] for k in r['other_kernels'] if 'update' in k['kernel']]} all {o} iters {d['solver_iters']['fwd']}+{d['solver_iters']['adj']} parity {d['parity_vs_oracle']['vs_exact_solution']['u_rel_err_max']:.2e} {d['parity_vs_oracle']['vs_exact_solution']['dkappa_rel_err_max']:.2e}", flush=True)
 PY
 }
 run cw2 X=1
