@@ -2262,6 +2262,7 @@ struct Hier {
   double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
   int nu, n_coarse, fmg_coarse_cycles;
   int fuse;  // 0: four single-stage strip passes per level; 1 / 2: fused two-stage passes, samples per lane
+  int dense_mfma;  // coarsest-level dense solve of an fp32 cycle on the matrix cores (0: scalar-load kernel)
   double coarse_lmax;  // upper bound of the spectrum of D^-1 A on the coarsest level (2 for an M-matrix)
   // per-level work vectors
   void *xa[kMaxLevels], *xb[kMaxLevels], *res[kMaxLevels], *rhs[kMaxLevels];  // TV vectors of the V-cycle
@@ -2520,7 +2521,7 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   if (L.inv && H.Bv == 1 && L.n <= kPartBlocks) {  // dense inverse of the shared level matrix: one launch
     diffhe::account(2.0 * sizeof(TV) * (double)L.n * H.Bp);
     static const int use_mfma = getenv("DIFFHE_DENSE_MFMA") ? atoi(getenv("DIFFHE_DENSE_MFMA")) : 1;
-    if (use_mfma && sizeof(TV) == 4 && H.Bp >= kWave && !part) {
+    if (use_mfma && H.dense_mfma && sizeof(TV) == 4 && H.Bp >= kWave && !part) {
       // 8 waves per 32 x 32 tile split the sum over j: 1089 nodes x 256 samples = 280 blocks, a chain of 17 dependent
       // 4-step groups per wave (4 waves: 28 us, the scalar fp64-accumulating kernel: 51 us)
       if (use_mfma == 4)
@@ -2886,6 +2887,7 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
   H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
   H.fuse = fused_mode();
+  H.dense_mfma = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
 }
@@ -2941,6 +2943,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const bool warm = (precond_fp32 & 32) != 0;   // x holds an initial guess (e.g. the previous step of an optimisation)
   H.fmg_coarse_cycles = 1 + ((precond_fp32 >> 2) & 3);
   if (precond_fp32 & 64) H.fuse = 0;             // bit 6: keep the four single-stage passes (A/B runs, tests)
+  if (precond_fp32 & 128) H.dense_mfma = 0;      // bit 7: scalar-load dense coarse solve
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;

@@ -383,7 +383,8 @@ class _Engine:
                                               int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
                                               | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
                                               | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0)
-                                              | (0 if int(mg.get("fused", 1)) else 64),
+                                              | (0 if int(mg.get("fused", 1)) else 64)
+                                              | (0 if int(mg.get("dense_mfma", 1)) else 128),
                                               _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters), _hip.ptr(rule),
                                               _hip.ptr(st), _stream(p.device)), "diffhe_lattice_pcg_solve")

@@ -288,6 +288,8 @@ typedef struct diffhe_mg_level {
  *            loop): the solve starts from x + FMG(b - A x) (bit 1 set) or from x itself;
  *            bit 6: keep the four single-stage strip passes per level in the fp32 V-cycle of a batch-shared matrix
  *            (default: the fused two-stage passes, 22 instead of 42 B per node and sample and cycle);
+ *            bit 7: coarsest-level dense solve of the fp32 cycle with the scalar-load kernel (fp64 accumulation)
+ *            instead of the MFMA kernel (fp32 accumulation; the default for batches of >= 64);
  *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at
  *            |r| <= max(tol |b|, 0.5 u |A_b| |x0_b|), u = 2^-53, |A_b| = 2 scale[b] max_i K_ii: fp64 cannot
  *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the

@@ -304,6 +304,33 @@ def test_adjoint_state_is_released_with_the_backward_pass_not_with_the_outputs()
     assert len(S._STATES) == n0 - 1 and u.grad_fn is not None
 
 
+# ---- coarsest-level dense solve on the matrix cores ---------------------------------------------------------------
+@pytest.mark.parametrize("mesh_fn,B", [(lambda: FEMesh.rectangle(256, 192, bc_value=0.25), 128), (lambda: FEMesh.rectangle(320, 288), 64)])
+def test_mfma_coarse_solve_agrees_with_the_scalar_kernel_and_the_oracle(mesh_fn, B):
+    """mg_dense_mfma_kernel (fp32 accumulation on v_mfma_f32_32x32x2_f32, A operand read through the symmetry of the
+    inverse) against the scalar-load kernel (fp64 accumulation): same iteration count, same u and dL/dkappa to 1e-10,
+    both within the parity tolerance of the oracle on two samples."""
+    mesh = mesh_fn()
+    g = torch.Generator().manual_seed(12)
+    k0 = torch.rand(B, generator=g, dtype=T64) * 1.5 + 0.5
+    f0 = torch.rand(B, mesh.n_nodes, generator=g, dtype=T64) + 0.5
+    out = {}
+    for tag, mg in (("mfma", None), ("scalar", dict(dense_mfma=0))):
+        out[tag] = _run(mesh, k0, f0, mg=mg)
+    um, gm, fm, im = out["mfma"]
+    us, gs, fs, is_ = out["scalar"]
+    assert im.path == "lattice-mgpcg" and im.iterations == is_.iterations and im.not_converged == 0
+    assert rel_err(um.cpu().numpy(), us.cpu().numpy()) < 1e-10 and rel_err(gm.cpu().numpy(), gs.cpu().numpy()) < 1e-10
+    bn = np.array(list(mesh.dirichlet_nodes.keys()))
+    bv = np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B - 1):
+        uo, dk, dfo = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, float(k0[b]), f0[b].numpy(),
+                                             lambda u_: 2 * u_, sparse=True)
+        assert rel_err(um[b].cpu().numpy(), uo) < RTOL_U
+        assert abs(float(gm[b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+        assert rel_err(fm[b].cpu().numpy(), dfo) < RTOL_GRAD
+
+
 # ---- lattice form of the gather assembly ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mesh_fn,B", [(lambda: FEMesh.rectangle(37, 29, bc_value=0.3), 64), (lambda: _skewed(40, 33, seed=2), 128),
                                        (lambda: FEMesh.rectangle(8, 5), 3)])
