@@ -1875,6 +1875,77 @@ __global__ __launch_bounds__(256) void mg_prolong_add_kernel(Level F, Level C, c
   }
 }
 
+// The two transfers for fp32 vectors, full coarsening and batches that are multiples of 128: a wave owns ONE node and 128
+// samples (8-byte accesses), the node index and everything derived from it (row / column, parities, Dirichlet flag,
+// coarse index) is wave-uniform scalar arithmetic instead of one integer division per lane.  Same fp64 arithmetic per
+// sample as mg_prolong_add_kernel / mg_restrict_kernel: bitwise the same values.
+__global__ __launch_bounds__(256) void mg_prolong2_kernel(Level F, Level C, const float* __restrict__ e,
+                                                           float* __restrict__ x, int Bp, int set) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (2 * kWave) + 2 * lane;
+  for (int i = blockIdx.x * 4 + wave; i < F.n; i += gridDim.x * 4) {
+    float* __restrict__ px = x + (i64)i * Bp + lb;
+    if (F.bc[i]) {
+      if (set) *(v2f*)px = v2f{0.0f, 0.0f};
+      continue;
+    }
+    const int fi = i / F.W, fj = i - fi * F.W;
+    const bool oi = fi & 1, oj = fj & 1;
+    const float* __restrict__ pe = e + ((i64)(fi >> 1) * C.W + (fj >> 1)) * Bp + lb;
+    double v0, v1;
+    if (!oi && !oj) {
+      const v2f a = *(const v2f*)pe;
+      v0 = (double)a.x; v1 = (double)a.y;
+    } else {
+      const v2f a = *(const v2f*)(pe + ((oi && oj) ? (i64)Bp : 0));                       // c (or c + 1 on a quad diagonal)
+      const v2f b = *(const v2f*)(pe + (!oi ? (i64)Bp : (i64)C.W * Bp));                  // c + 1 (odd column only) or c + C.W
+      v0 = 0.5 * ((double)a.x + (double)b.x);
+      v1 = 0.5 * ((double)a.y + (double)b.y);
+    }
+    if (set) {
+      *(v2f*)px = v2f{(float)v0, (float)v1};
+    } else {
+      const v2f o = *(const v2f*)px;
+      *(v2f*)px = v2f{(float)((double)o.x + v0), (float)((double)o.y + v1)};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mg_restrict2_kernel(Level F, Level C, const float* __restrict__ r,
+                                                            float* __restrict__ rc, int Bp) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (2 * kWave) + 2 * lane;
+  for (int I = blockIdx.x * 4 + wave; I < C.n; I += gridDim.x * 4) {
+    float* __restrict__ po = rc + (i64)I * Bp + lb;
+    if (C.bc[I]) {
+      *(v2f*)po = v2f{0.0f, 0.0f};
+      continue;
+    }
+    const int ci = I / C.W, cj = I - ci * C.W;
+    const int fi = 2 * ci, fj = 2 * cj;
+    const float* __restrict__ pc = r + ((i64)fi * F.W + fj) * Bp + lb;
+    const i64 row = (i64)F.W * Bp;
+    double h0 = 0.0, h1 = 0.0;
+    auto acc = [&](const float* q) { const v2f t = *(const v2f*)q; h0 += (double)t.x; h1 += (double)t.y; };
+    if (fj > 0) acc(pc - Bp);
+    if (fj < F.nx) acc(pc + Bp);
+    if (fi > 0) acc(pc - row);
+    if (fi < F.ny) acc(pc + row);
+    if (fi > 0 && fj < F.nx) acc(pc - row + Bp);
+    if (fi < F.ny && fj > 0) acc(pc + row - Bp);
+    const v2f cc = *(const v2f*)pc;
+    *(v2f*)po = v2f{(float)((double)cc.x + 0.5 * h0), (float)((double)cc.y + 0.5 * h1)};
+  }
+}
+
+inline bool transfers2_ok(const Level& F, const Level& C, int Bp, size_t esz) {
+  static const int on = getenv("DIFFHE_TRANSFER2") ? atoi(getenv("DIFFHE_TRANSFER2")) : 1;
+  return on && esz == 4 && F.nx == 2 * C.nx && F.ny == 2 * C.ny && Bp % (2 * kWave) == 0;
+}
+inline dim3 transfer2_grid(int n, int Bp) { return dim3((unsigned)(((i64)n + 3) / 4 < 4096 ? ((i64)n + 3) / 4 : 4096), Bp / (2 * kWave)); }
+
 // per-element kappa of the coarse triangulation.  Full coarsening (sx = sy = 2): mean of the 4 children
 // (Galerkin for nested P1).  Semi-coarsening: both coarse triangles of a cell take the mean of the 4 fine
 // triangles of the 2 fine cells it covers.
@@ -2568,6 +2639,26 @@ TV* coarse_solve(const Hier& H, int l, const TV* rhs, double* part, int* nblocks
   return xa;
 }
 
+template <typename TV>
+void launch_restrict(const Hier& H, const Level& F, const Level& C, const TV* r, TV* rc, hipStream_t st) {
+  if (transfers2_ok(F, C, H.Bp, sizeof(TV))) {
+    diffhe::account(((double)F.n / C.n + 1.0) * sizeof(TV) * (double)C.n * H.Bp);
+    hipLaunchKernelGGL(mg_restrict2_kernel, transfer2_grid(C.n, H.Bp), dim3(256), 0, st, F, C, (const float*)r, (float*)rc, H.Bp);
+  } else {
+    LAUNCH(((double)F.n / C.n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, C.n, F, C, r, rc, H.Bp);
+  }
+}
+
+template <typename TV>
+void launch_prolong(const Hier& H, const Level& F, const Level& C, const TV* e, TV* x, int set, hipStream_t st) {
+  if (transfers2_ok(F, C, H.Bp, sizeof(TV))) {
+    diffhe::account(((set ? 1.0 : 2.0) + (double)C.n / F.n) * sizeof(TV) * (double)F.n * H.Bp);
+    hipLaunchKernelGGL(mg_prolong2_kernel, transfer2_grid(F.n, H.Bp), dim3(256), 0, st, F, C, (const float*)e, (float*)x, H.Bp, set);
+  } else {
+    LAUNCH(((set ? 1.0 : 2.0) + (double)C.n / F.n) * sizeof(TV), mg_prolong_add_kernel<TV>, F.n, F, C, e, x, H.Bp, set);
+  }
+}
+
 // residual + full-weighting restriction of level l in one pass (the residual is never stored): H.rhs[l + 1] = R (rhs - A x)
 template <typename TV>
 void resid_restrict(const Hier& H, int l, const TV* x, const TV* rhs_l, hipStream_t st) {
@@ -2722,7 +2813,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         resid_restrict<TV>(H, l, a, rhs[l], st);
       } else {
         op_residual<TV>(H, l, rhs[l], a, (TV*)H.res[l], nullptr, st);
-        LAUNCH(((double)L.n / C.n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, C.n, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], H.Bp);
+        launch_restrict<TV>(H, L, C, (const TV*)H.res[l], (TV*)H.rhs[l + 1], st);
       }
       rhs[l + 1] = (const TV*)H.rhs[l + 1];
     }
@@ -2762,7 +2853,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       TV* t = a; a = b2; b2 = t;
       s0 = 1;
     } else {
-      LAUNCH((2.0 + (double)C.n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, C, (const TV*)cur[l + 1], a, H.Bp);
+      launch_prolong<TV>(H, L, C, (const TV*)cur[l + 1], a, 0, st);
     }
     for (int s = s0; s < H.nu; ++s) {
       const bool lastsweep = (l == l0 && s == H.nu - 1);
@@ -2786,7 +2877,7 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st, const TV** pending = 
   const TV* bl[kMaxLevels];
   bl[0] = b0;
   for (int l = 0; l < last; ++l) {
-    LAUNCH(((double)H.lev[l].n / H.lev[l + 1].n + 1.0) * sizeof(TV), mg_restrict_kernel<TV>, H.lev[l + 1].n, H.lev[l], H.lev[l + 1], bl[l], (TV*)H.bF[l + 1], H.Bp);
+    launch_restrict<TV>(H, H.lev[l], H.lev[l + 1], bl[l], (TV*)H.bF[l + 1], st);
     bl[l + 1] = (const TV*)H.bF[l + 1];
   }
   {  // coarsest level: the V-cycle from `last` is n_coarse Jacobi sweeps
@@ -2816,7 +2907,7 @@ TV* fmg_start(const Hier& H, const TV* b0, hipStream_t st, const TV** pending = 
       if (diffhe::check(hipMemcpyAsync(x, it, (size_t)L.n * H.Bp * sizeof(TV), hipMemcpyDeviceToDevice, st))) return nullptr;
       c0 = 1;
     } else {
-      LAUNCH((1.0 + (double)H.lev[l + 1].n / L.n) * sizeof(TV), mg_prolong_add_kernel<TV>, L.n, L, H.lev[l + 1], coarse, x, H.Bp, 1);
+      launch_prolong<TV>(H, L, H.lev[l + 1], coarse, x, 1, st);
     }
     for (int c = c0; c < cycles; ++c) {
       op_residual<TV>(H, l, bl[l], (const TV*)x, (TV*)H.rhs[l], nullptr, st);
