@@ -712,6 +712,7 @@ KERNEL_SYMBOLS_FP32 = ["dia_strip_kernel<double, float, double, 0, 4, 3, true, f
 
 
 KERNEL_NAME_CGSTEP_NOAP = "fused CG step: p = z + beta p stored, p.Ap with A p kept in registers (never stored; 12 B)"
+KERNEL_SYMBOL_CGSTEP2 = "cgstep2_kernel<float __vector(2), 3, 4, 8>"
 KERNEL_NAME_RUPD = "residual update with A p recomputed from the stored p: r -= alpha A p, r.r, fp32 copy of r (24 B)"
 KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, false, 4, 5>"
 
@@ -737,6 +738,8 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     symbols = list(KERNEL_SYMBOLS_FUSED if fused else KERNEL_SYMBOLS_FP32)
     if rupd:
         symbols[1] = KERNEL_SYMBOL_RUPD
+        if fused:      # two samples per lane (multiples of 128): the packed-fp32 CG step
+            symbols[0] = KERNEL_SYMBOL_CGSTEP2
     have = [sy for sy, (ms_, n_) in zip(symbols, kprof) if n_ > 0]
     traffic, src = pmc_traffic(have, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")
     names = list(KERNEL_NAMES_FUSED if fused else KERNEL_NAMES)

@@ -1580,6 +1580,104 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L
   }
 }
 
+// ---- CG step of a batch-shared matrix with fp32-stored directions, two samples per lane -------------------------------
+// p = z + beta p_old (fp32 fused multiply-add: the stored value), p . (K_1 p) with the stencil in packed fp32 on the fp32
+// coefficient copies, accumulated per sample in fp64; A p itself is never stored (the residual update recomputes it in
+// fp64 from the stored p, F_RUPD).  The fp32 stencil only enters the STEP LENGTH alpha = r.z / p.Ap: x += alpha p and
+// r -= alpha A p use the same alpha and the exact (fp64) A p, so r = b - A x holds to fp64 whatever alpha is, and an
+// error delta in alpha costs delta^2 of the energy reduction of the step (the minimum of a parabola).
+template <typename VT, int ND, int RW, bool EDGE>
+__device__ __forceinline__ void cgstep2_body(const Level& L, VT beta, bool first, const float* __restrict__ z,
+                                             const float* __restrict__ pin, float* __restrict__ pout, int Bp, unsigned lb,
+                                             int c0w, int r0, int r1, double& s0, double& s1) {
+  constexpr int N = RW + 2;                  // window columns c0w - 1 + j
+  const int W = L.W, nyp = L.ny + 1;
+  const i64 n = L.n;
+  const VT Z = VLane<VT>::zero();
+  const Coef<VT, true> cf(L, 0, lb, Bp);
+  bool ok[N];
+  unsigned off[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    int c = c0w - 1 + j;
+    ok[j] = !EDGE || (c >= 0 && c < W);
+    if (EDGE) c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+    off[j] = 4u * ((unsigned)(c - (c0w - 1) + 1) * (unsigned)Bp + lb);      // base sits one column further left
+  }
+  const i64 tile0 = ((i64)(r0 - 1) * W + (c0w - 2)) * Bp;                  // element (r0 - 1, c0w - 2)
+  const rsrc_t rz = make_rsrc(z + tile0);
+  const rsrc_t rp = make_rsrc(first ? z + tile0 : pin + tile0);
+  const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;
+  auto p_row = [&](int R, VT* dst) {
+    if (EDGE && (R < 0 || R >= nyp)) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) dst[j] = Z;
+      return;
+    }
+    const unsigned sx = (unsigned)(R - (r0 - 1)) * rowB;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      VT v = VLane<VT>::ld(rz, off[j], sx);
+      if (!first) v += beta * VLane<VT>::ld(rp, off[j], sx);
+      dst[j] = ok[j] ? v : Z;
+    }
+  };
+  VT a0[N], a1[N], a2[N];
+  p_row(r0 - 1, a0);
+  p_row(r0, a1);
+  float* __restrict__ pp = pout + ((i64)r0 * W + c0w) * Bp;
+  for (int row = r0; row < r1; ++row) {
+    p_row(row + 1, a2);
+    k1_row<VT, RW, ND, EDGE>(cf, n, W, row, c0w, a0, a1, a2, [&](int k, VT kx, float, float) {
+      if (!EDGE || c0w + k < W) {
+        __builtin_nontemporal_store(a1[k + 1], (VT*)(pp + (i64)k * Bp + lb));
+        VLane<VT>::dot(s0, s1, a1[k + 1], kx);
+      }
+    });
+    pp += (i64)W * Bp;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+  }
+}
+
+template <typename VT, int ND, int RW, int MW>
+__global__ __launch_bounds__(256, MW) void cgstep2_kernel(Level L, const double* __restrict__ scale,
+                                                           const double* __restrict__ beta, int first,
+                                                           const float* __restrict__ z, const float* __restrict__ pin,
+                                                           float* __restrict__ pout, double* __restrict__ part, int Bp,
+                                                           int ncb, int TR) {
+  __shared__ double lds[4 * kWave];
+  constexpr int SPL = VLane<VT>::kSpl;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = blockIdx.y * (SPL * kWave) + SPL * lane;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int rc = tile / ncb, cb = tile - rc * ncb;
+  const int nyp = L.ny + 1;
+  const int c0w = (cb * 4 + wave) * RW;
+  const int r0 = rc * TR;
+  const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
+  double s0 = 0.0, s1 = 0.0;
+  if (c0w < L.W && r0 < r1) {
+    VT bt = VLane<VT>::zero();
+    if (!first) {
+      if constexpr (SPL == 2) bt = VT{(float)beta[lb], (float)beta[lb + 1]};
+      else bt = (float)beta[lb];
+    }
+    const bool edge = c0w - 1 < 0 || c0w + RW > L.W - 1 || r0 - 1 < 0 || r1 > nyp - 1;
+    if (edge) cgstep2_body<VT, ND, RW, true>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, s0, s1);
+    else cgstep2_body<VT, ND, RW, false>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, s0, s1);
+  }
+  const double f0 = scale ? scale[lb] : 1.0;
+  const double t0 = block_sum_per_sample(s0 * f0, Bp, lds);
+  if (wave == 0) part[(i64)blockIdx.x * Bp + lb] = t0;
+  if (SPL == 2) {
+    const double f1 = scale ? scale[lb + 1] : 1.0;
+    const double t1 = block_sum_per_sample(s1 * f1, Bp, lds);
+    if (wave == 0) part[(i64)blockIdx.x * Bp + lb + 1] = t1;
+  }
+}
+
 constexpr int kStripCols = 8;
 // fp32-stored V-cycle vectors run best on 4-column strips (kernel trace, same box: prolongation + sweep -7 %,
 // first two sweeps -5 % against 8 columns); fp64 vectors keep 8 (half the register footprint per column there)
@@ -1603,6 +1701,7 @@ inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols, int spl
   g.use = true;
   g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
   const int gy = Bp / (kWave * spl);   // spl = samples per lane (2: dia_strip2_kernel)
+  if (gy < 1) { g.use = false; return g; }   // fewer samples than one wave of that form holds
   static const int target = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
   int nrc = (target + g.ncb * gy - 1) / (g.ncb * gy);
   const int nyp = L.ny + 1;
@@ -3141,6 +3240,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const int rupd_mode = rupd_env();
   const bool rupd = fused && f32 && Bv == 1 && rupd_mode != 0;
   const StripGeom g8 = strip_geom(L0, Bp, 8);
+  // two samples per lane (cgstep2_kernel): batches that are multiples of 128 only
+  const StripGeom g2 = (Bp % (2 * kWave) == 0) ? strip_geom(L0, Bp, 4, 2) : StripGeom{false, 0, 0, 0};
   const void* z = nullptr;
   int it = 0, flushed = 0;       // iterations done / directions already folded into x (fused loop)
   // x += sum_{j = flushed .. it-1} alpha_j p_j  (+ z / rs at the end of the solve: pcg_finish_kernel)
@@ -3177,6 +3278,28 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   launch_strip<double, M_APPLY, false, F_PUPD_NX, float, RW_, MINW_>(L0, Bv, scale, (const double*)nullptr,                \
                                                                       (const double*)nullptr, rupd ? (double*)nullptr : Ap, \
                                                                       0.0, 0.0, partA, Bp, g0, st, ex)
+      static const int cg2 = getenv("DIFFHE_CG2") ? atoi(getenv("DIFFHE_CG2")) : 1;
+      // flag bit 8: the caller vouches for a lattice closed by Dirichlet data (lambda_min of the scaled operator bounded
+      // away from 0).  With large Neumann parts the search directions are dominated by near-null modes, for which the
+      // fp32 stencil cancels to noise: measured 13 / 11 instead of 12 / 9 iterations to 1e-14 there (gpurun_out/r6g)
+      if (f32 && rupd && cg2 && (precond_fp32 & 256) && g2.use && strip2_ok(L0, Bv, Bp) &&
+          strip2_tile_fits(L0, Bp, g2.TR + 3)) {
+        // two samples per lane, packed fp32 stencil for p.Ap (cgstep2_kernel): the step length only
+        const dim3 grid(g2.ncb * g2.nrc, Bp / (2 * kWave));
+        diffhe::account((first ? 8.0 : 12.0) * (double)n * Bp);
+        const float* zz = (const float*)z;
+        const float* pi_ = (const float*)ex.p_in;
+        float* po_ = (float*)ex.p_out;
+#define CG2(ND_, MW_) hipLaunchKernelGGL((cgstep2_kernel<v2f, ND_, 4, MW_>), grid, dim3(256), 0, st, L0, scale, \
+                                         (const double*)S.beta, first, zz, pi_, po_, partA, Bp, g2.ncb, g2.TR)
+        // 8 waves per SIMD: 0.70 ms at 1024^2 x 256 (6: 0.75, 4: 0.75; the one-sample fp64 strip: 0.87; gpurun_out/r6e)
+        if (L0.nd == 3) CG2(3, 8); else CG2(4, 8);
+#undef CG2
+        S.alpha = alpha_ring + (long long)(it % n_slots) * Bp;
+        nba = g2.ncb * g2.nrc;
+        if (!first) kp_end(KP_CGSTEP, st);
+        return;
+      }
       if (f32) {
         // 72 VGPRs (18 spilled), 7 waves per SIMD: 1.16 ms against 1.28 at the compiler's own 85 / 5; 8-column strips
         // (142 VGPRs) 1.96, 2-column strips at 8 waves 1.27, 6 or 8 waves 1.25 / 1.18 (same box, gpurun_out/r2l/variants*.txt).

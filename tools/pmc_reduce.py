@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "fused_pre_kernel", "fused_post_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
+KEEP = ("__amd_rocclr_copyBuffer", "dia_strip_kernel", "dia_strip2_kernel", "fused_pre_kernel", "fused_post_kernel", "cgstep2_kernel", "mg_prolong2_kernel", "mg_restrict2_kernel", "mg_dense_mfma_kernel", "dia_jacobi_kernel", "pcg_update_kernel", "pcg_setx_kernel",
         "pcg_cvt_kernel", "pcg_axpy_kernel", "pcg_finish_kernel", "to_node_major_kernel", "to_sample_major_kernel",
         "cg_spmv_kernel", "ell_jacobi_kernel", "ell_galerkin_kernel", "ell_residual_out_kernel", "agg_restrict_kernel",
         "sa_prolong_add_kernel", "amg_update_kernel", "assemble_rows_kernel", "lattice_grad_kappa_kernel",
@@ -71,7 +71,7 @@ def main():
         for key, label, passes in RULES:
             if key in k:
                 out["kernels"][k].update(label=label, algorithmic_passes=passes,
-                                         traffic_over_algorithmic=(rd + wr) / pass_bytes / passes)
+                                         traffic_over_algorithmic=((rd + wr) / pass_bytes / passes) if passes > 0 else None)
                 break
     text = json.dumps(out, indent=1)
     if len(sys.argv) > 3:

@@ -18,6 +18,7 @@ RULES = [
     ("dia_strip_kernel<double, float, double, 0, 5", "residual update, A p recomputed from p: r -= alpha A p, r.r, fp32 copy of r", 3.0),
     ("dia_strip_kernel<double, double, double, 0, 4", "fused CG step, z/p fp64", 4.0),
     ("dia_strip_kernel<double, float, double, 0, 2", "fused CG step with the x update (isolated launches of bench.py only)", 4.5),
+    ("cgstep2_kernel", "fused CG step, two samples per lane (p = z + beta p stored, p.Ap with a packed-fp32 stencil; A p never stored)", 1.5),
     ("pcg_update_kernel", "r -= alpha Ap, r.r (+ fp32 copy of r)", 3.5),
     ("fused_pre_kernel", "fused PRE pass: two sweeps from 0 + residual + restriction (fp32, two samples per lane)", 1.125),
     ("fused_post_kernel", "fused POST pass: prolongation + correction + two sweeps (fp32, two samples per lane)", 1.625),
