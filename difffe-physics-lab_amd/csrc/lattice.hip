@@ -3282,6 +3282,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       // flag bit 8: the caller vouches for a lattice closed by Dirichlet data (lambda_min of the scaled operator bounded
       // away from 0).  With large Neumann parts the search directions are dominated by near-null modes, for which the
       // fp32 stencil cancels to noise: measured 13 / 11 instead of 12 / 9 iterations to 1e-14 there (gpurun_out/r6g)
+      // (the host also asks for near-square cells and a hierarchy that reaches the dense coarsest level: on a 382 x 259
+      // lattice, which coarsens once, 36 iterations to 1e-14 became 38 -- tools/stress.py seed 6301 case 39)
       if (f32 && rupd && cg2 && (precond_fp32 & 256) && g2.use && strip2_ok(L0, Bv, Bp) &&
           strip2_tile_fits(L0, Bp, g2.TR + 3)) {
         // two samples per lane, packed fp32 stencil for p.Ap (cgstep2_kernel): the step length only

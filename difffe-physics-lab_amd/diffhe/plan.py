@@ -454,6 +454,7 @@ class SolvePlan:
         self.levels = []
         self.n_bc_interior = 0
         self.closed_boundary = False
+        self.regular_cells = False
         # --- 1D chain fast path ---------------------------------------------------------
         self.is_lattice = False
         self.is_chain = bool(self.dim == 1 and self.n == self.m + 1
@@ -481,6 +482,16 @@ class SolvePlan:
             # every node of the four edges is a Dirichlet node (what FEMesh.rectangle produces): the regime in which
             # the energy norm controls nodal values and a scalar kappa per sample may stay factored
             self.closed_boundary = bool(bc2d[0, :].all() and bc2d[-1, :].all() and bc2d[:, 0].all() and bc2d[:, -1].all())
+            # cells close to square and axis-aligned (what FEMesh.rectangle on a near-square domain gives): where the
+            # multigrid cycle converges at its textbook rate and the CG may take its step LENGTH from an fp32 stencil
+            # (cgstep2_kernel; the solver also asks for a full hierarchy: where multigrid converges slowly an inexact
+            # step length costs iterations)
+            dx = np.abs(np.diff(nodes2d[:, :, 0], axis=1))
+            dy = np.abs(np.diff(nodes2d[:, :, 1], axis=0))
+            skew = max(float(np.abs(np.diff(nodes2d[:, :, 1], axis=1)).max(initial=0.0)),
+                       float(np.abs(np.diff(nodes2d[:, :, 0], axis=0)).max(initial=0.0)))
+            hmin, hmax = min(float(dx.min()), float(dy.min())), max(float(dx.max()), float(dy.max()))
+            self.regular_cells = bool(hmin > 0 and hmax <= 2.0 * hmin and skew <= 1e-12 * hmax)
             while len(self.levels) < 16:
                 self.levels.append(LatticeLevel(nodes2d, bc2d, device, with_load_matrix=not self.levels))
                 step = coarsening_step(nodes2d)

@@ -385,7 +385,8 @@ class _Engine:
                                               | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0)
                                               | (0 if int(mg.get("fused", 1)) else 64)
                                               | (0 if int(mg.get("dense_mfma", 1)) else 128)
-                                              | (256 if (p.closed_boundary and int(mg.get("cg_fp32_steplength", 1))) else 0),
+                                              | (256 if (p.closed_boundary and p.regular_cells and p.dense_level() is not None
+                                                         and int(mg.get("cg_fp32_steplength", 1))) else 0),
                                               _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters), _hip.ptr(rule),
                                               _hip.ptr(st), _stream(p.device)), "diffhe_lattice_pcg_solve")

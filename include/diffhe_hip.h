@@ -290,7 +290,8 @@ typedef struct diffhe_mg_level {
  *            (default: the fused two-stage passes, 22 instead of 42 B per node and sample and cycle);
  *            bit 7: coarsest-level dense solve of the fp32 cycle with the scalar-load kernel (fp64 accumulation)
  *            instead of the MFMA kernel (fp32 accumulation; the default for batches of >= 64);
- *            bit 8: the lattice is closed by Dirichlet data on all four edges: the CG step of a batch-shared matrix may
+ *            bit 8: the lattice is closed by Dirichlet data on all four edges, its cells are near-square and its
+ *            hierarchy reaches a small coarsest level (multigrid at its textbook rate): the CG step of a batch-shared matrix may
  *            form p.Ap -- the step length only -- with a packed-fp32 stencil, two samples per lane (cgstep2_kernel);
  *            x and r are updated with the exact fp64 A p either way;
  *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at

@@ -127,6 +127,13 @@ for case in range(n_cases):
         print(solver.last_info, "n_bc", len(bn), "tol", solver.tol)
     worst = max(worst, e)
     flag = "" if e < 1e-10 else "   <-- ABOVE 1e-10"
+    extra = ""
+    if os.environ.get("STRESS_VERBOSE"):
+        from diffhe.plan import get_plan
+        pl = get_plan(mesh, torch.device("cuda:0"))
+        xy = mesh.nodes.numpy()
+        extra = (f"  closed={getattr(pl, 'closed_boundary', None)} regular={getattr(pl, 'regular_cells', None)} "
+                 f"extent={np.ptp(xy, axis=0)} adj_iters={solver.last_info.adj_iterations} rules={solver.last_info.stop_rules}")
     print(f"case {case:3d} {kind:12s} n={n:5d} B={B:3d} kappa={kmode:11s} path={solver.last_info.path:14s} "
-          f"iters={solver.last_info.iterations:4d} err={e:.1e}{flag}", flush=True)
+          f"iters={solver.last_info.iterations:4d} err={e:.1e}{flag}{extra}", flush=True)
 print("worst", worst)
