@@ -304,6 +304,34 @@ def test_adjoint_state_is_released_with_the_backward_pass_not_with_the_outputs()
     assert len(S._STATES) == n0 - 1 and u.grad_fn is not None
 
 
+# ---- fp32 step length of the CG (cgstep2_kernel) -----------------------------------------------------------------------
+def test_fp32_step_length_is_used_only_where_multigrid_is_fast_and_changes_nothing_there():
+    """Flag bit 8 of diffhe_lattice_pcg_solve: the host sets it for lattices closed by Dirichlet data with near-square
+    cells and a full hierarchy.  There the two-samples-per-lane CG step (p.Ap from a packed-fp32 stencil -- the step
+    length only) gives the iteration counts and, to 1e-10, the results of the fp64 one-sample step."""
+    dev = torch.device(DEV)
+    good = get_plan(FEMesh.rectangle(256, 192), dev)
+    assert good.closed_boundary and good.regular_cells and good.dense_level() is not None
+    stretched = get_plan(FEMesh.rectangle(256, 192, x_range=(0.0, 6.0)), dev)
+    assert stretched.closed_boundary and not stretched.regular_cells
+    assert not get_plan(_skewed(64, 64, seed=1), dev).regular_cells
+    shallow = get_plan(FEMesh.rectangle(382, 259), dev)                   # coarsens once: no small coarsest level
+    assert shallow.closed_boundary and shallow.regular_cells and shallow.dense_level() is None
+    open_edge = FEMesh.rectangle(64, 64)
+    d = {k: v for k, v in open_edge.dirichlet_nodes.items() if k > 64}    # bottom edge left free
+    assert not get_plan(FEMesh(nodes=open_edge.nodes, elements=open_edge.elements, dirichlet_nodes=d), dev).closed_boundary
+
+    mesh, B = FEMesh.rectangle(256, 192, bc_value=0.1), 128
+    g = torch.Generator().manual_seed(21)
+    k0 = torch.rand(B, generator=g, dtype=T64) * 1.5 + 0.5
+    f0 = torch.rand(B, mesh.n_nodes, generator=g, dtype=T64) + 0.5
+    a = _run(mesh, k0, f0)
+    b = _run(mesh, k0, f0, mg=dict(cg_fp32_steplength=0))
+    assert a[3].iterations == b[3].iterations and a[3].adj_iterations == b[3].adj_iterations and a[3].not_converged == 0
+    for x, y in zip(a[:3], b[:3]):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-10
+
+
 # ---- coarsest-level dense solve on the matrix cores ---------------------------------------------------------------
 @pytest.mark.parametrize("mesh_fn,B", [(lambda: FEMesh.rectangle(256, 192, bc_value=0.25), 128), (lambda: FEMesh.rectangle(320, 288), 64)])
 def test_mfma_coarse_solve_agrees_with_the_scalar_kernel_and_the_oracle(mesh_fn, B):
