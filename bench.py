@@ -91,6 +91,82 @@ def spawn_ranks(args) -> int:
     return rc
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes():
+    """NUMA node of every GPU in KFD enumeration order (= HIP device order unless *_VISIBLE_DEVICES remaps it), read from
+    sysfs only -- no HIP call, so it may run before the process touches the GPU.  [] when the topology is not readable."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    out = []
+    try:
+        for name in sorted(os.listdir(base), key=int):
+            props = {}
+            for line in open(os.path.join(base, name, "properties")):
+                k, _, v = line.partition(" ")
+                props[k] = v.strip()
+            if int(props.get("simd_count", "0")) == 0:
+                continue                                   # a CPU node
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            try:
+                out.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+            except (OSError, ValueError):
+                out.append(-1)
+    except (OSError, ValueError):
+        return []
+    return out
+
+
+def rank_cpu_slice(allowed, world, local_rank, gpu_numa=(), node_cpus=None):
+    """Host cores of rank `local_rank`: the cores of its GPU's NUMA node (shared evenly with the other ranks whose GPU
+    sits on the same node), else an even contiguous slice of the allowed cores.  Pure function (tested on CPU)."""
+    allowed = sorted(allowed)
+    node_cpus = node_cpus or {}
+    if gpu_numa and local_rank < len(gpu_numa) and gpu_numa[local_rank] >= 0 and gpu_numa[local_rank] in node_cpus:
+        node = gpu_numa[local_rank]
+        peers = [r for r in range(min(world, len(gpu_numa))) if gpu_numa[r] == node]
+        pool = [c for c in allowed if c in node_cpus[node]]
+        if len(pool) >= len(peers):
+            k = peers.index(local_rank)
+            per = len(pool) // len(peers)
+            return pool[k * per:(k + 1) * per]
+    per = len(allowed) // world
+    if per < 1:
+        return allowed
+    return allowed[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(world, local_rank):
+    """One process per GPU: keep this rank's host threads (Python, the HIP runtime's helper threads, autograd's
+    thread) on the cores next to its GPU.  Every solve reads one int per CG iteration from the host; with N ranks
+    wandering over all cores that wait grows.  Called before anything touches the GPU.  Never fatal."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        numa = gpu_numa_nodes()
+        node_cpus = {}
+        for node in set(numa):
+            if node >= 0:
+                try:
+                    node_cpus[node] = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+                except OSError:
+                    pass
+        cpus = rank_cpu_slice(allowed, world, local_rank, numa, node_cpus)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"cores": len(cpus), "first": min(cpus) if cpus else None,
+                "numa_node": numa[local_rank] if local_rank < len(numa) else None}
+    except (OSError, ValueError, AttributeError) as exc:
+        return {"error": type(exc).__name__}
+
+
 def _spread(xs):
     xs = sorted(float(x) for x in xs)
     return {"min": round(xs[0], 3), "median": round(statistics.median(xs), 3), "max": round(xs[-1], 3)}
@@ -105,9 +181,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    affinity = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        affinity = pin_rank(world, local_rank)       # before torch is imported, before any GPU call
         # the mesh plan's host arrays (gather lists, reference-order integrals: ~5 s of numpy at 1024^2) are built by
         # rank 0 and mapped by the other ranks of the node (diffhe.plan.host_arrays)
         os.environ.setdefault("DIFFHE_PLAN_CACHE", os.path.join(
@@ -403,7 +481,11 @@ def main():
             "metric": f"FEM solves/sec (fwd+adjoint), 2D P1 Poisson {N}^2 mesh, batch={B} per GPU",
             "value": round(value, 4), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "dtype_detail": ("f64 iterate / residual / reductions; fp32-stored preconditioner with packed-fp32 arithmetic, fp32 "
+                             "stencil in the CG step length only (config.precision); all-fp64 storage: "
+                             "variants.vcycle_storage_fp64") if fp32 else "f64 storage and arithmetic throughout",
+            "data": "synthetic",
             "config": {"workload": f"C4: rectangle({N},{N}), {B} samples/GPU, "
                                    + {"sample": "kappa_b~U(0.5,2) scalar per sample, ",
                                       "element": "per-element log-normal kappa field per sample, ",
@@ -422,17 +504,21 @@ def main():
                                             "note": "|b - A x| / |b| of the RETURNED iterate, recomputed after the solve"},
                        "multigrid": {k: v for k, v in solver.mg.items() if v is not None},
                        "operator": ("FACTORED: K_b = kappa_b * K_1, one shared unit matrix + a per-sample scale (zero "
-                                    "matrix traffic; not bit-identical to the reference's sum_e kappa_b k0_e, 4e-13 in u "
-                                    "here); every sample is solved by its own PCG, no u(1)/kappa shortcut.  The general "
+                                    "matrix traffic; not bit-identical to the reference's sum_e kappa_b k0_e, whose "
+                                    "rounded diagonal moves the exact solution by ~cond * eps: "
+                                    + (f"measured distance to the refined oracle in this run u {parity['u_rel_err']:.1e}, "
+                                       f"dL/dkappa {parity['dkappa_rel_err']:.1e}" if parity and "u_rel_err" in parity
+                                       else "3e-11 in u / 8e-11 in dL/dkappa at 1024^2, see parity_vs_oracle of a run with "
+                                            "the CPU baseline")
+                                    + "); every sample is solved by its own PCG, no u(1)/kappa shortcut.  The general "
                                     "case -- a per-element field per sample, one matrix per sample -- is "
                                     "variants.kappa_element_field") if args.kappa == "sample" else
                                    ("one assembled matrix per sample and level" if args.kappa == "element" else
                                     "one assembled matrix shared by the batch (per-element field, nothing factored)"),
-                       "precision": ("fp64 arithmetic, iterate x, residual r, A p and every dot product; the CG search "
-                                     "direction p and the V-cycle (preconditioner) vectors are STORED fp32")
-                                    if fp32 else "fp64 throughout",
+                       "precision": head_info.precision or ("fp64 throughout" if not fp32 else "see solver.last_info"),
+                       "solver_flags": head_info.flags, "vcycle_coefficients": head_info.coeff_storage,
                        "parallelism": f"batch-sharded x{world} (diffhe.distributed.ShardedBatchSolve, fused loss all-reduce)",
-                       "plan_build_s": round(t_plan, 2)},
+                       "plan_build_s": round(t_plan, 2), "rank_affinity": affinity},
             "solver_iters": {"fwd": max(r_[0] for r_ in it) if it else None, "adj": max(r_[1] for r_ in it) if it else None,
                              "max_relres_fwd": max(r_[2] for r_ in it) if it else None,
                              "max_relres_adj": max(r_[3] for r_ in it) if it else None,
@@ -762,12 +848,31 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     copy_gbs = 16.0 * n * Bp / (e0.elapsed_time(e1) * 1e-3 / args.kernel_reps) / 1e9
     del x, y
     top = table[0]
+    # the dominant PHASE next to the dominant kernel: the V-cycle's passes together outweigh any single kernel
+    vnames = set(names[2:6])
+    vc = [row for row in table if row["kernel"] in vnames]
+    phase = None
+    if vc:
+        v_ms = sum(r_["total_ms_timed"] for r_ in vc)
+        v_bytes = sum(r_["bytes_per_launch"] * r_["launches_timed"] for r_ in vc)
+        all_ms = sum(r_["total_ms_timed"] for r_ in table)
+        v_traffic = [r_["traffic"] for r_ in vc]
+        phase = {"phase": "V-cycle (preconditioner) passes on the fine level: " + " + ".join(r_["kernel"].split(":")[0] for r_ in vc),
+                 "total_ms_timed": round(v_ms, 3), "share_of_the_timed_kernels": round(v_ms / all_ms, 3),
+                 "achieved": round(v_bytes / (v_ms * 1e-3) / 1e9, 1),
+                 "frac": round(v_bytes / (v_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "traffic_over_algorithmic": (round(sum(t_ * r_["launches_timed"] for t_, r_ in zip(v_traffic, vc)) / v_bytes, 3)
+                                              if all(t_ is not None for t_ in v_traffic) else None),
+                 "note": "aggregate algorithmic bytes / aggregate in-solver time of these launches; the coarser levels' "
+                         "launches of the same kernels are not in these events (profiles/*_step_budget.txt has them)"}
     return {"bound": "hbm", "kernel": top["kernel"], "symbol": top["symbol"], "achieved": top["achieved"],
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"], "traffic": top["traffic"], "traffic_source": src,
             "bytes_per_launch": top["bytes_per_launch"], "avg_launch_ms": top["avg_launch_ms"],
             "launches_timed": top["launches_timed"],
             "dominance": "largest in-solver total among the six main kernels of an iteration (HIP events on the solve's "
-                         "stream, fine-level launches of the forward solves in the timed steps)",
+                         "stream, fine-level launches of the forward solves in the timed steps); the dominant PHASE -- the "
+                         "V-cycle's passes together -- is `dominant_phase`",
+            "dominant_phase": phase,
             "stream_copy_gbs": round(copy_gbs, 1),
             "stream_ceiling_note": "profiles/r02_stream_bench.txt: 4.7-5.6 TB/s for 1R1W..2R2W mixes, 6.3-6.5 read-only",
             "other_kernels": table[1:]}

@@ -27,10 +27,11 @@ struct Level {
   int nx, ny, n, W, nd;
   const double* v;          // (nd, n, Bv)
   const float* v32;         // optional fp32 copy of v, used by the fp32 V-cycle's strip kernels
-  const _Float16* o16;      // optional fp16 off-diagonals (nd - 1, n, Bv), times 1 / oscale, of a per-sample matrix (Bv == Bp):
+  const _Float16* o16;      // optional fp16 off-diagonals (nd - 1, n, Bv), times 1 / osc[b], of a per-sample matrix (Bv == Bp):
                             // with it v32 holds ONLY the main diagonal (n, Bv), adjusted so that every row sum equals
                             // the fp64 matrix's
-  double oscale;            // power of two >= the largest diagonal entry: stored off-diagonals lie in [-1, 1]
+  const double* osc;        // (Bv) per-sample powers of two >= the sample's largest free-row diagonal entry: stored
+                            // off-diagonals lie in [-1, 1] whatever the magnitude of that sample's kappa
   const float* rd32;        // optional (n) fp32 reciprocal of the main diagonal of a batch-SHARED level matrix (Bv == 1):
                             // with v32 and mk32 it switches the fp32 V-cycle to the two-samples-per-lane strip kernels
   const float* mk32;        // (n) 0.0f on Dirichlet rows, 1.0f elsewhere (scalar-loadable form of bc)
@@ -47,9 +48,12 @@ __device__ inline double shift_at(const Level& L, int i) { return L.shift ? L.sh
 // be spectrally close to A: rounding an edge weight to fp16 (2^-11 relative) while the diagonal keeps every ROW SUM of
 // the fp64 matrix perturbs A by a graph Laplacian with edge weights 2^-11 |a_ij| -- spectrally equivalent within 0.1 %,
 // the null-space behaviour of the smooth modes untouched (a rounded diagonal would shift them by 2^-11 |a_ii| >>
-// lambda_min).  Range: the off-diagonals are stored divided by a power of two >= the largest diagonal entry (|a_ij| <=
-// max a_ii for an SPD matrix), so kappa of any magnitude fits; bf16 (no scaling needed) was measured one PCG iteration
-// worse on the bench workload (10 + 10 against 9 + 9).
+// lambda_min).  Range: the off-diagonals of sample b are stored divided by a power of two >= that sample's largest
+// free-row diagonal entry (|a_ij| <= max a_ii for an SPD matrix), so kappa of any magnitude -- and samples of very
+// different magnitudes in one batch -- fit; what fp16 cannot hold is contrast INSIDE a sample: couplings below
+// 2^-19 of the scale keep fewer than 5 bits (subnormals) and flush to 0 below 2^-25, so the packing kernel reports them and
+// the host falls back to plain fp32 copies for that solve (dia_pack_h16_kernel).  bf16 (no scaling needed) was measured
+// one PCG iteration worse on the bench workload (10 + 10 against 9 + 9).
 struct h16m {};   // tag type
 template <typename TM> struct MatTypes { typedef TM diag; typedef TM off; };
 template <> struct MatTypes<h16m> { typedef float diag; typedef _Float16 off; };
@@ -234,8 +238,8 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
   double s = 0.0;
 
   // Column offsets of the window (q <-> grid column c0w - 1 + q) and of the strip (k <-> c0w + k),
-  // relative to column c0w.  Only the left halo of the first strip and the columns past the right
-  // edge (TAIL) are clamped; their window values are forced to 0.
+  // relative to column c0w.  The first strip's left halo and the columns past the right edge are clamped (both
+  // only in the TAIL instantiation, which every edge strip takes); their window values are forced to 0.
   int dq[RW + 2];
   bool okq[RW + 2];
 #pragma unroll
@@ -246,13 +250,14 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     if (TAIL && c > W - 1) c = W - 1;
     dq[q] = c - c0w;
   }
-  // D_k[i] lives at V[(k*n + i)*Bv + vb]; for k >= 1 a negative i (>= -n) still indexes valid,
-  // finite memory (the previous diagonal) and is only ever multiplied by a window value of 0.
+  // D_k[i] lives at V[(k*n + i)*Bv + vb].  Row r0 - 1 of D_2 / D_3 is read for the south couplings also when r0 == 0:
+  // that is the tail of the previous diagonal in the same array (finite, multiplied by a window value of 0).  Nothing is
+  // read in front of an array: the east coupling of column c0w - 1 is an in-grid entry for every non-TAIL strip.
   const i64 i0 = (i64)r0 * W + c0w;          // node (r0, c0w)
   typedef typename MatTypes<TM>::diag TD;
   typedef typename MatTypes<TM>::off TO;
-  constexpr bool kSplit = sizeof(TO) == 2;   // h16m: diagonal in L.v32, off-diagonals in L.o16 (times 1 / L.oscale)
-  const double osc = kSplit ? L.oscale : 1.0;
+  constexpr bool kSplit = sizeof(TO) == 2;   // h16m: diagonal in L.v32, off-diagonals in L.o16 (times 1 / L.osc[b])
+  const double osc = kSplit ? L.osc[b] : 1.0;
   const TD* __restrict__ p0 = (sizeof(TD) == 4 ? (const TD*)L.v32 : (const TD*)L.v) + i0 * Bv;
   const TO* __restrict__ p1 = kSplit ? (const TO*)L.o16 + i0 * Bv : (const TO*)(const void*)(p0 + n * Bv);
   const TO* __restrict__ p2 = p1 + n * Bv;
@@ -361,8 +366,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
     }
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) {
-      // east coupling of column c0w-1+k; column -1 reads the element before the row (valid
-      // memory, multiplied by a zero window value)
+      // east coupling of column c0w - 1 + k (interior strips: c0w >= RW, the column exists; edge strips: clamped)
       const int dc = TAIL ? dq[k] : k - 1;
       e1[k] = kSplit ? osc * ldc(p1 + (i64)dc * Bv, lv) : ldc(p1 + (i64)dc * Bv, lv);
       d3c[k] = (ND == 4) ? (kSplit ? osc * ldc(p3 + (i64)dq[k + 1] * Bv, lv) : ldc(p3 + (i64)dq[k + 1] * Bv, lv)) : 0.0;
@@ -534,7 +538,9 @@ __device__ __forceinline__ void strip_kernel_body(Level L, const double* __restr
   const TV* __restrict__ src = XFROMB ? bvec : xin;
   double s = 0.0, s2 = 0.0;
   if (active) {
-    if (c0w + RW + 1 > L.W || c0w < 0)
+    // strips that touch the left or right edge take the clamped body -- the first strip (c0w == 0) too: its window column
+    // -1 would otherwise read the east coupling one element BEFORE the row, which for row 0 lies in front of the array
+    if (c0w + RW + 1 > L.W || c0w <= 0)
       s = strip_body<TV, TA, TM, MODE, FUSE, ND, SHARED, XFROMB, RW, true, SHIFT>(L, sb, src, bvec, out, omega, omega_in, ex,
                                                                               Bp, b, c0w, r0, r1, s2);
     else
@@ -726,7 +732,7 @@ __device__ __forceinline__ void strip2_body(const Level& L, v2f ib, v2f sb, cons
     }
 #pragma unroll
     for (int k = 0; k < RW + 1; ++k) {
-      const int dc = TAIL ? dq[k] : k - 1;  // east coupling of column c0w-1+k (column -1: valid memory x a zero window value)
+      const int dc = TAIL ? dq[k] : k - 1;  // east coupling of column c0w - 1 + k (TAIL covers c0w < 1: clamped)
       e1[k] = p1[dc];
       d3c[k] = (ND == 4) ? p3[dq[k + 1]] : 0.0f;
     }
@@ -895,6 +901,26 @@ __global__ __launch_bounds__(256) void dia_strip2_kernel(Level L, const double* 
 // fp32), evaluated once more on the halo ring; results agree with them to fp32 rounding (different association only).
 // A wave owns its columns for both stages; VT = v2f (two samples per lane) or float (one).
 // ---------------------------------------------------------------------------------------------
+// per-sample sum over the NW waves of a block (lanes hold distinct samples); valid in wave 0.  NW == 4: the same order
+// of additions as block_sum_per_sample (results of the default geometry stay bitwise what they were)
+template <int NW>
+__device__ __forceinline__ double block_sum_waves(double v, double* lds /* >= NW * 64 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  lds[wave * kWave + lane] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (wave == 0) {
+    if (NW == 4) {
+      s = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += lds[w * kWave + lane];
+    }
+  }
+  __syncthreads();
+  return s;
+}
+
 template <typename VT> struct VLane;
 template <> struct VLane<float> {
   static constexpr int kSpl = 1;
@@ -921,7 +947,7 @@ template <> struct VLane<v2f> {
 
 // Where the matrix coefficients of the fused passes come from.
 //   SHARED: batch-shared fp32 copies + reciprocal diagonal, wave-uniform scalar loads (values are plain floats);
-//   per sample: fp32 diagonal + scaled fp16 off-diagonals (Level.v32 / o16 / oscale), one value per sample and lane,
+//   per sample: fp32 diagonal + scaled fp16 off-diagonals (Level.v32 / o16 / osc), one value per sample and lane,
 //   buffer loads with tile-relative offsets; the reciprocal diagonal is v_rcp_f32 of the loaded diagonal.
 template <typename VT, bool SHARED> struct Coef;
 template <typename VT> struct Coef<VT, true> {
@@ -960,9 +986,9 @@ template <typename VT> struct Coef<VT, false> {
   rsrc_t r0, r1, r2, r3;
   i64 base;       // node index the resources are based at (<= every index the tile touches)
   unsigned lb, Bp;
-  float osc;
+  VT osc;         // this lane's sample scale(s) of the fp16 couplings
   __device__ __forceinline__ Coef(const Level& L, i64 base_, unsigned lb_, int Bp_)
-      : base(base_), lb(lb_), Bp((unsigned)Bp_), osc((float)L.oscale) {
+      : base(base_), lb(lb_), Bp((unsigned)Bp_), osc(VLane<VT>::from_scale(L.osc, lb_)) {
     const i64 n = L.n;
     r0 = make_rsrc(L.v32 + base * Bp_);
     r1 = make_rsrc(L.o16 + base * Bp_);
@@ -1293,8 +1319,11 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
   }
 }
 
-template <typename VT, int ND, int CW, bool SHARED>
-__global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_pre_kernel(Level L, const double* __restrict__ scale,
+// NW = waves per block: a block owns NW * CW adjacent coarse columns.  What reaches the fabric is each BLOCK's footprint
+// once (PMC: neighbouring blocks do not share their halo columns in L2), so wider blocks cut the column halo: 4 waves read
+// (16 + 4) / 16 of x, 8 waves (32 + 4) / 32, 16 waves (64 + 4) / 64.
+template <typename VT, int ND, int CW, bool SHARED, int NW = 4>
+__global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_pre_kernel(Level L, const double* __restrict__ scale,
                                                          const float* __restrict__ rhs, float* __restrict__ x2out,
                                                          float* __restrict__ crhs, float w0, float w1, int cW,
                                                          const unsigned char* __restrict__ cbc, int Bp, int ncb, int TR) {
@@ -1305,7 +1334,7 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_pre_kernel(Level L,
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int rc = tile / ncb, cb = tile - rc * ncb;
   const int nyp = L.ny + 1;
-  const int J0 = (cb * 4 + wave) * CW, I0 = rc * TR;
+  const int J0 = (cb * NW + wave) * CW, I0 = rc * TR;
   const int cnyp = (nyp + 1) >> 1;
   const int I1 = (I0 + TR < cnyp) ? I0 + TR : cnyp;
   if (!(J0 < cW && I0 < I1)) return;
@@ -1540,13 +1569,13 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
 
 // XZ: the operand is P e alone (x = 0 is not read): two sweeps from a prolonged initial guess, the first stage of a
 // full-multigrid level (vcycle with `guess`)
-template <typename VT, int ND, int RW, bool DOT, bool SHARED, bool XZ = false>
-__global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
+template <typename VT, int ND, int RW, bool DOT, bool SHARED, bool XZ = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
                                                           float wB, int cW, double* __restrict__ part, int Bp, int ncb,
                                                           int TR) {
-  __shared__ double lds[4 * kWave];
+  __shared__ double lds[NW * kWave];
   constexpr int SPL = VLane<VT>::kSpl;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1554,7 +1583,7 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int rc = tile / ncb, cb = tile - rc * ncb;
   const int nyp = L.ny + 1;
-  const int c0w = (cb * 4 + wave) * RW;
+  const int c0w = (cb * NW + wave) * RW;
   const int r0 = rc * TR;
   const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
   const bool active = c0w < L.W && r0 < r1;
@@ -1570,11 +1599,11 @@ __global__ __launch_bounds__(256, SHARED ? 4 : 1) void fused_post_kernel(Level L
   }
   if (DOT) {
     const double f0 = scale ? scale[lb] : 1.0;
-    const double t0 = block_sum_per_sample(s0 * f0, Bp, lds);
+    const double t0 = block_sum_waves<NW>(s0 * f0, lds);
     if (wave == 0) part[(i64)blockIdx.x * Bp + lb] = t0;
     if (SPL == 2) {
       const double f1 = scale ? scale[lb + 1] : 1.0;
-      const double t1 = block_sum_per_sample(s1 * f1, Bp, lds);
+      const double t1 = block_sum_waves<NW>(s1 * f1, lds);
       if (wave == 0) part[(i64)blockIdx.x * Bp + lb + 1] = t1;
     }
   }
@@ -1692,17 +1721,18 @@ struct StripGeom {
   int ncb, nrc, TR;
 };
 
-inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols, int spl = 1) {
+inline StripGeom strip_geom(const Level& L, int Bp, int rw = kStripCols, int spl = 1, int nw = 4) {
   StripGeom g{false, 0, 0, 0};
   // small levels: one wave marching down a strip is latency-bound; the simple kernels win below ~200^2
   // 128: the 129^2 level of a 1024^2 hierarchy takes the strip / fused kernels too (-0.7 ms per step; 64: slower again)
   static const int minw = getenv("DIFFHE_STRIP_MINW") ? atoi(getenv("DIFFHE_STRIP_MINW")) : 128;
   if (Bp < kWave || L.W < minw || L.ny + 1 < 64) return g;
   g.use = true;
-  g.ncb = (L.W + 4 * rw - 1) / (4 * rw);
+  g.ncb = (L.W + nw * rw - 1) / (nw * rw);   // nw = waves (strips) per block
   const int gy = Bp / (kWave * spl);   // spl = samples per lane (2: dia_strip2_kernel)
   if (gy < 1) { g.use = false; return g; }   // fewer samples than one wave of that form holds
-  static const int target = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
+  static const int target4 = getenv("DIFFHE_STRIP_BLOCKS") ? atoi(getenv("DIFFHE_STRIP_BLOCKS")) : 6144;
+  const int target = target4 * 4 / nw;       // the same number of WAVES (and tile height) whatever the block width
   int nrc = (target + g.ncb * gy - 1) / (g.ncb * gy);
   const int nyp = L.ny + 1;
   if (nrc > nyp / 8) nrc = nyp / 8;
@@ -1753,10 +1783,11 @@ void launch_strip(const Level& L, int Bv, const double* scale, const TV* xin, co
 
 // fp32 V-cycle, batch-shared matrix with fp32 coefficient copies and reciprocal diagonal, batch a multiple of 128,
 // no diagonal shift: the two-samples-per-lane kernels apply (DIFFHE_STRIP2=0 switches them off: A/B runs)
-inline bool strip2_ok(const Level& L, int Bv, int Bp) {
+inline bool shared32_ok(const Level& L, int Bv, int Bp) {   // the fp32 copies of a batch-shared matrix are there, whole waves
   static const int on = getenv("DIFFHE_STRIP2") ? atoi(getenv("DIFFHE_STRIP2")) : 1;
-  return on && Bv == 1 && L.v32 && L.rd32 && L.mk32 && !L.shift && Bp % (2 * kWave) == 0;
+  return on && Bv == 1 && L.v32 && L.rd32 && L.mk32 && !L.shift && Bp % kWave == 0;
 }
+inline bool strip2_ok(const Level& L, int Bv, int Bp) { return shared32_ok(L, Bv, Bp) && Bp % (2 * kWave) == 0; }
 // the kernels address their tile (`rows` fine rows + the window's two halo rows) with 32-bit byte offsets
 inline bool strip2_tile_fits(const Level& L, int Bp, int rows) { return 4LL * (rows + 3) * L.W * Bp < (1LL << 31); }
 // geometry for the two-samples-per-lane kernels if they apply to this level (and its tiles fit), else the usual one
@@ -1832,7 +1863,9 @@ inline int env_level_int(const char* name, int level) {
 }
 
 inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
-  if (strip2_ok(L, Bv, Bp)) return 3;
+  // batch-shared matrix: two samples per lane for multiples of 128, else ONE per lane (batches of 64 or 192 per GPU --
+  // BASELINE config 5's shard: same fused passes, fp32 arithmetic, 4-byte accesses)
+  if (shared32_ok(L, Bv, Bp)) return 3;
   // per-sample matrices: both passes fused, with the coefficient rows cached in registers (fp16 couplings as raw words:
   // 174 / 206 VGPRs, 2 waves per SIMD, no spills).  Without the cache the PRE pass needed 256 VGPRs and measured slower
   // than its two single passes (forward solve 153 ms against 140), and the POST pass re-read every coefficient row four
@@ -1842,30 +1875,41 @@ inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
   return (Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale) ? per_sample : 0;
 }
 
+// waves per block of the fused passes of a batch-shared matrix (4, 8 or 16; per-sample matrices keep 4)
+inline int fused_nw() {
+  static const int v = getenv("DIFFHE_FUSED_NW") ? atoi(getenv("DIFFHE_FUSED_NW")) : 4;
+  return (v == 8 || v == 16) ? v : 4;
+}
+
 void launch_fused_pre(const Level& L, const Level& C, int Bv, const double* scale, const float* rhs, float* x2, float* crhs,
-                      double w0, double w1, int Bp, const StripGeom& g, int spl, hipStream_t st) {
+                      double w0, double w1, int Bp, const StripGeom& g, int spl, hipStream_t st, int nw = 4) {
   constexpr int CW = kRestrictCols;
   // r read, x2 and the coarse rhs written; per-sample matrices: + the compact coefficients (read by both stages)
   diffhe::account((9.0 + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPRE(VT_, ND_, SH_)                                                                                               \
-  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW, SH_>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,     \
-                     (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
+#define FPREN(VT_, ND_, SH_, NW_)                                                                                         \
+  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW, SH_, NW_>), grid, dim3(64 * NW_), fused_lds(), st, L, scale, rhs, x2, \
+                     crhs, (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
+#define FPRE(VT_, ND_, SH_) FPREN(VT_, ND_, SH_, 4)
   if (Bv != 1) { if (L.nd == 3) FPRE(v2f, 3, false); else FPRE(v2f, 4, false); }
+  else if (spl == 2 && nw == 8 && L.nd == 3) FPREN(v2f, 3, true, 8);
+  else if (spl == 2 && nw == 16 && L.nd == 3) FPREN(v2f, 3, true, 16);
   else if (spl == 2) { if (L.nd == 3) FPRE(v2f, 3, true); else FPRE(v2f, 4, true); }
   else { if (L.nd == 3) FPRE(float, 3, true); else FPRE(float, 4, true); }
 #undef FPRE
+#undef FPREN
 }
 
 void launch_fused_post(const Level& L, const Level& C, int Bv, const double* scale, const float* xin, const float* rhs,
                        const float* ec, float* z, double wA, double wB, double* part, int Bp, const StripGeom& g, int spl,
-                       hipStream_t st) {
+                       hipStream_t st, int nw = 4) {
   // x2, r, a quarter of e read; z written (+ compact coefficients of a per-sample matrix); xin == NULL: x2 = 0, not read
   diffhe::account(((xin ? 13.0 : 9.0) + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPOST(VT_, ND_, DOT_, SH_, XZ_)                                                                                      \
-  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_, XZ_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, \
-                     z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+#define FPOSTN(VT_, ND_, DOT_, SH_, XZ_, NW_)                                                                                \
+  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_, XZ_, NW_>), grid, dim3(64 * NW_), fused_lds(), st, L, scale, xin, \
+                     rhs, ec, z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+#define FPOST(VT_, ND_, DOT_, SH_, XZ_) FPOSTN(VT_, ND_, DOT_, SH_, XZ_, 4)
 #define FPOSTD(VT_, ND_, SH_)                                                                                              \
   do {                                                                                                                     \
     if (!xin) FPOST(VT_, ND_, false, SH_, true);                                                                          \
@@ -1873,10 +1917,21 @@ void launch_fused_post(const Level& L, const Level& C, int Bv, const double* sca
     else FPOST(VT_, ND_, false, SH_, false);                                                                              \
   } while (0)
   if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
+  else if (spl == 2 && (nw == 8 || nw == 16) && L.nd == 3) {
+#define FPOSTDN(NW_)                                                                                                       \
+  do {                                                                                                                     \
+    if (!xin) FPOSTN(v2f, 3, false, true, true, NW_);                                                                      \
+    else if (part) FPOSTN(v2f, 3, true, true, false, NW_);                                                                 \
+    else FPOSTN(v2f, 3, false, true, false, NW_);                                                                          \
+  } while (0)
+    if (nw == 8) FPOSTDN(8); else FPOSTDN(16);
+#undef FPOSTDN
+  }
   else if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
   else { if (L.nd == 3) FPOSTD(float, 3, true); else FPOSTD(float, 4, true); }
 #undef FPOSTD
 #undef FPOST
+#undef FPOSTN
 }
 
 // One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
@@ -2790,6 +2845,13 @@ void resid_restrict(const Hier& H, int l, const TV* x, const TV* rhs_l, hipStrea
   if (l == 0) kp_end(KP_RESTRICT, st);
 }
 
+// waves per block of the fused passes on level L: the wide blocks for the two-samples-per-lane kernels of a batch-shared
+// 3-diagonal matrix on levels wide enough to fill them
+inline int fused_nw_for(const Hier& H, const Level& L) {
+  const int nw = fused_nw();
+  return (H.Bv == 1 && H.fuse == 2 && L.nd == 3 && L.W > 300) ? nw : 4;
+}
+
 // Can level l of the fp32 cycle run the fused POST pass (and with it the initial-guess form of the cycle)?  Fills the
 // tile geometries of the fused PRE (gpre) and POST (gpost) passes; returns the fused_ok mask (0: no fused pass here).
 template <typename TV>
@@ -2800,11 +2862,12 @@ int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
   const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
   if (!fmask || !(L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use)) return 0;
   const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
+  const int nw = fused_nw_for(H, L);
   constexpr int CW = kRestrictCols;
   StripGeom g{true, 0, 0, 0};
-  g.ncb = (C.W + 4 * CW - 1) / (4 * CW);
+  g.ncb = (C.W + nw * CW - 1) / (nw * CW);
   const int gy = H.Bp / (spl * kWave);
-  int nrc = (6144 + g.ncb * gy - 1) / (g.ncb * gy);
+  int nrc = (6144 * 4 / nw + g.ncb * gy - 1) / (g.ncb * gy);
   // Levels of <= 300 columns cannot fill the GPU with 4-coarse-row tiles: shorter tiles (2 coarse rows going down, ~5 fine
   // rows going up) double the independent marches; -1.4 ms per 1024^2 step, neutral on the 513^2 level (gpurun_out/r5j, r5k)
   const bool small = L.W <= 300;
@@ -2815,7 +2878,7 @@ int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
   if (const int tr = env_level_int("DIFFHE_FUSED_TR_PRE", l)) g.TR = tr;
   g.nrc = (C.ny + 1 + g.TR - 1) / g.TR;
   *gpre = g;
-  *gpost = strip_geom(L, H.Bp, 4, spl);
+  *gpost = strip_geom(L, H.Bp, 4, spl, nw);
   if (small) {
     const int nyp = L.ny + 1;
     int tr = 4;
@@ -2869,7 +2932,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       if (l == l0 && guess && fused[l]) {
         // two sweeps from the prolonged guess (the POST kernel with x = 0), then residual + restriction
         launch_fused_post(L, C, H.Bv, H.scale, (const float*)nullptr, (const float*)rhs[l], (const float*)guess, (float*)a,
-                          H.omega[0], H.omega[1], nullptr, H.Bp, gpost[l], spl, st);
+                          H.omega[0], H.omega[1], nullptr, H.Bp, gpost[l], spl, st, fused_nw_for(H, L));
         resid_restrict<TV>(H, l, a, rhs[l], st);
         cur[l] = a;
         rhs[l + 1] = (const TV*)H.rhs[l + 1];
@@ -2879,7 +2942,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         // both sweeps + residual + restriction in ONE pass (fused_pre_kernel)
         if (l == 0) kp_begin(KP_FIRST2, st);
         launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
-                         H.omega[1], H.Bp, gpre, spl, st);
+                         H.omega[1], H.Bp, gpre, spl, st, fused_nw_for(H, L));
         if (l == 0) kp_end(KP_FIRST2, st);
         cur[l] = a;
         rhs[l + 1] = (const TV*)H.rhs[l + 1];
@@ -2926,7 +2989,8 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       const bool dot = (l == l0) && rz_part;
       if (l == 0) kp_begin(KP_PROLONG, st);
       launch_fused_post(L, C, H.Bv, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
-                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.Bv == 1 ? H.fuse : 2, st);
+                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.Bv == 1 ? H.fuse : 2, st,
+                        fused_nw_for(H, L));
       if (l == 0) kp_end(KP_PROLONG, st);
       if (dot && rz_blocks) *rz_blocks = gpost[l].ncb * gpost[l].nrc;
       cur[l] = b2;
@@ -3070,13 +3134,14 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
     if ((long long)(s.nx + 1) * (s.ny + 1) > 0x7fffffffLL) return DIFFHE_E_TOOBIG;
     Level& L = H.lev[l];
     L.nx = s.nx; L.ny = s.ny; L.W = s.nx + 1; L.n = (s.nx + 1) * (s.ny + 1); L.nd = s.nd;
-    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32; L.mk32 = s.mask32; L.o16 = (Bv == Bp && Bp > 1 && s.offdiag_scale > 0.0) ? (const _Float16*)s.offdiag16 : nullptr;
-    L.oscale = s.offdiag_scale;
+    L.v = s.vals; L.v32 = s.vals32; L.bc = s.is_bc; L.inv = s.dense_inv; L.shift = s.shift; L.rd32 = s.rdiag32; L.mk32 = s.mask32; L.o16 = (Bv == Bp && Bp > 1 && s.offdiag_scales) ? (const _Float16*)s.offdiag16 : nullptr;
+    L.osc = s.offdiag_scales;
   }
   H.nl = n_levels; H.Bv = Bv; H.Bp = Bp; H.scale = scale; H.nu = nu; H.n_coarse = n_coarse;
   H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
   H.fuse = fused_mode();
+  if (H.fuse == 2 && Bp % (2 * kWave) != 0) H.fuse = 1;   // one sample per lane where the batch is no multiple of 128
   H.dense_mfma = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
@@ -3240,8 +3305,9 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const int rupd_mode = rupd_env();
   const bool rupd = fused && f32 && Bv == 1 && rupd_mode != 0;
   const StripGeom g8 = strip_geom(L0, Bp, 8);
-  // two samples per lane (cgstep2_kernel): batches that are multiples of 128 only
-  const StripGeom g2 = (Bp % (2 * kWave) == 0) ? strip_geom(L0, Bp, 4, 2) : StripGeom{false, 0, 0, 0};
+  // cgstep2_kernel: two samples per lane for batches that are multiples of 128, else one
+  const int cspl = (Bp % (2 * kWave) == 0) ? 2 : 1;
+  const StripGeom g2 = (Bp % kWave == 0) ? strip_geom(L0, Bp, 4, cspl) : StripGeom{false, 0, 0, 0};
   const void* z = nullptr;
   int it = 0, flushed = 0;       // iterations done / directions already folded into x (fused loop)
   // x += sum_{j = flushed .. it-1} alpha_j p_j  (+ z / rs at the end of the solve: pcg_finish_kernel)
@@ -3284,18 +3350,19 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       // fp32 stencil cancels to noise: measured 13 / 11 instead of 12 / 9 iterations to 1e-14 there (gpurun_out/r6g)
       // (the host also asks for near-square cells and a hierarchy that reaches the dense coarsest level: on a 382 x 259
       // lattice, which coarsens once, 36 iterations to 1e-14 became 38 -- tools/stress.py seed 6301 case 39)
-      if (f32 && rupd && cg2 && (precond_fp32 & 256) && g2.use && strip2_ok(L0, Bv, Bp) &&
+      if (f32 && rupd && cg2 && (precond_fp32 & 256) && g2.use && shared32_ok(L0, Bv, Bp) &&
           strip2_tile_fits(L0, Bp, g2.TR + 3)) {
-        // two samples per lane, packed fp32 stencil for p.Ap (cgstep2_kernel): the step length only
-        const dim3 grid(g2.ncb * g2.nrc, Bp / (2 * kWave));
+        // fp32 stencil for p.Ap (cgstep2_kernel; packed, two samples per lane, where the batch allows): the step length only
+        const dim3 grid(g2.ncb * g2.nrc, Bp / (cspl * kWave));
         diffhe::account((first ? 8.0 : 12.0) * (double)n * Bp);
         const float* zz = (const float*)z;
         const float* pi_ = (const float*)ex.p_in;
         float* po_ = (float*)ex.p_out;
-#define CG2(ND_, MW_) hipLaunchKernelGGL((cgstep2_kernel<v2f, ND_, 4, MW_>), grid, dim3(256), 0, st, L0, scale, \
-                                         (const double*)S.beta, first, zz, pi_, po_, partA, Bp, g2.ncb, g2.TR)
+#define CG2(VT_, ND_, MW_) hipLaunchKernelGGL((cgstep2_kernel<VT_, ND_, 4, MW_>), grid, dim3(256), 0, st, L0, scale, \
+                                              (const double*)S.beta, first, zz, pi_, po_, partA, Bp, g2.ncb, g2.TR)
         // 8 waves per SIMD: 0.70 ms at 1024^2 x 256 (6: 0.75, 4: 0.75; the one-sample fp64 strip: 0.87; gpurun_out/r6e)
-        if (L0.nd == 3) CG2(3, 8); else CG2(4, 8);
+        if (cspl == 2) { if (L0.nd == 3) CG2(v2f, 3, 8); else CG2(v2f, 4, 8); }
+        else { if (L0.nd == 3) CG2(float, 3, 8); else CG2(float, 4, 8); }
 #undef CG2
         S.alpha = alpha_ring + (long long)(it % n_slots) * Bp;
         nba = g2.ncb * g2.nrc;
@@ -3518,7 +3585,7 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   if (sub && sub_B != 1 && sub_B != Bp) return DIFFHE_E_BADARG;
   Level L{};   // inv, shift: none
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
-  L.rd32 = nullptr; L.mk32 = nullptr; L.o16 = nullptr; L.oscale = 0.0;
+  L.rd32 = nullptr; L.mk32 = nullptr; L.o16 = nullptr; L.osc = nullptr;
   const StripGeom g = strip_geom(L, Bp);
   if (g.use && (!sub || sub_B == 1)) {
     Extra ex{};
@@ -3642,15 +3709,22 @@ extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const
   return diffhe::check_launch();
 }
 
-// fp32 diagonal + fp16 off-diagonals of a per-sample symmetric-diagonal matrix (h16m above): off-diagonals divided by
-// `oscale` and rounded to fp16, the diagonal moved by the sum of the rounding differences of the row's 2 (nd - 1)
-// couplings so that the row sum is the fp64 matrix's (to the fp32 rounding of the diagonal itself, 6e-8 relative).
-__global__ __launch_bounds__(256) void dia_pack_h16_kernel(Level L, int Bv, double oscale, float* __restrict__ d32,
-                                                            _Float16* __restrict__ o16) {
+// fp32 diagonal + fp16 off-diagonals of a per-sample symmetric-diagonal matrix (h16m above): the off-diagonals of sample b
+// divided by `oscale[b]` and rounded to fp16, the diagonal moved by the sum of the rounding differences of the row's
+// 2 (nd - 1) couplings so that the row sum is the fp64 matrix's (to the fp32 rounding of the diagonal itself, 6e-8
+// relative).  flags[0] is set when a non-zero coupling falls below 2^-19 of its sample's scale: fp16 subnormals keep fewer
+// than 5 bits there (and flush to 0 from 2^-25 on: the row-sum rule would then leave a row with a vanishing diagonal), so
+// the caller must not use the packed copies of that matrix (high contrast INSIDE a sample; the fp32 copies have no such limit).
+__global__ __launch_bounds__(256) void dia_pack_h16_kernel(Level L, int Bv, const double* __restrict__ oscale,
+                                                            float* __restrict__ d32, _Float16* __restrict__ o16,
+                                                            int* __restrict__ flags) {
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
   const i64 n = L.n;
-  const double inv = 1.0 / oscale;   // power of two: exact
+  const double osc = oscale[nm.b];
+  const double inv = 1.0 / osc;   // power of two: exact
+  const double tiny = 1.9073486328125e-06;   // 2^-19
+  bool under = false;
   for (int i = nm.node0; i < L.n; i += nm.stride) {
     double d = L.v[(i64)i * Bv + nm.b];
 #pragma unroll
@@ -3660,28 +3734,64 @@ __global__ __launch_bounds__(256) void dia_pack_h16_kernel(Level L, int Bv, doub
         const double up = L.v[((i64)k * n + i) * Bv + nm.b];            // coupling (i, i + off): stored here
         const _Float16 h = (_Float16)(float)(up * inv);
         o16[((i64)(k - 1) * n + i) * Bv + nm.b] = h;
-        if (i + off < L.n) d += up - oscale * (double)(float)h;
+        if (i + off < L.n) {
+          d += up - osc * (double)(float)h;
+          under = under || (up != 0.0 && fabs(up * inv) < tiny);
+        }
         if (i - off >= 0) {                                             // coupling (i - off, i): stored at the other end
           const double lo = L.v[((i64)k * n + (i - off)) * Bv + nm.b];
-          d += lo - oscale * (double)(float)(_Float16)(float)(lo * inv);
+          d += lo - osc * (double)(float)(_Float16)(float)(lo * inv);
         }
       }
     }
     d32[(i64)i * Bv + nm.b] = (float)d;
   }
+  if (flags && __any(under) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
 }
 
-extern "C" int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, double offdiag_scale, float* diag32,
-                                       void* offdiag16, void* stream) {
-  if (!level || !diag32 || !offdiag16 || !level->vals || (level->nd != 3 && level->nd != 4) || !(offdiag_scale > 0.0))
+extern "C" int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, const double* offdiag_scales, float* diag32,
+                                       void* offdiag16, int* flags, void* stream) {
+  if (!level || !diag32 || !offdiag16 || !level->vals || (level->nd != 3 && level->nd != 4) || !offdiag_scales)
     return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
   Level L{};
   L.nx = level->nx; L.ny = level->ny; L.W = level->nx + 1; L.n = (level->nx + 1) * (level->ny + 1); L.nd = level->nd;
   L.v = level->vals;
   diffhe::account((8.0 * L.nd + 4.0 + 2.0 * (L.nd - 1)) * (double)L.n * Bv);
-  hipLaunchKernelGGL(dia_pack_h16_kernel, node_grid(L.n, Bv), dim3(256), 0, (hipStream_t)stream, L, Bv, offdiag_scale,
-                     diag32, (_Float16*)offdiag16);
+  hipLaunchKernelGGL(dia_pack_h16_kernel, node_grid(L.n, Bv), dim3(256), 0, (hipStream_t)stream, L, Bv, offdiag_scales,
+                     diag32, (_Float16*)offdiag16, flags);
+  return diffhe::check_launch();
+}
+
+// Per-sample maximum of the main diagonal over the FREE rows (identity rows of Dirichlet nodes carry 1.0 whatever the
+// magnitude of kappa and are skipped): the quantity the per-sample fp16 scale is derived from.  out: Bv doubles.
+__global__ __launch_bounds__(256) void dia_maxdiag_free_kernel(Level L, int Bv, unsigned long long* __restrict__ out) {
+  const NodeMap nm = node_map(Bv);
+  double m = 0.0;
+  if (nm.b < Bv)
+    for (int i = nm.node0; i < L.n; i += nm.stride) {
+      const double d = L.bc[i] ? 0.0 : L.v[(i64)i * Bv + nm.b];
+      m = d > m ? d : m;
+    }
+  const int LB = Bv < kWave ? Bv : kWave;
+  for (int off = LB; off < kWave; off <<= 1) {  // lanes that hold the same sample
+    const double o = __shfl_xor(m, off);
+    m = o > m ? o : m;
+  }
+  if ((int)(threadIdx.x & 63) < LB && nm.b < Bv) atomicMax(out + nm.b, (unsigned long long)__double_as_longlong(m));
+}
+
+extern "C" int diffhe_lattice_max_diag(const diffhe_mg_level* level, int Bv, double* out, void* stream) {
+  if (!level || !out || !level->vals || !level->is_bc || (level->nd != 3 && level->nd != 4)) return DIFFHE_E_BADARG;
+  if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
+  Level L{};
+  L.nx = level->nx; L.ny = level->ny; L.W = level->nx + 1; L.n = (level->nx + 1) * (level->ny + 1); L.nd = level->nd;
+  L.v = level->vals; L.bc = level->is_bc;
+  int rc = diffhe::check(hipMemsetAsync(out, 0, sizeof(double) * Bv, (hipStream_t)stream));
+  if (rc) return rc;
+  diffhe::account(8.0 * (double)L.n * Bv);
+  hipLaunchKernelGGL(dia_maxdiag_free_kernel, node_grid(L.n, Bv, 512), dim3(256), 0, (hipStream_t)stream, L, Bv,
+                     (unsigned long long*)out);
   return diffhe::check_launch();
 }
 

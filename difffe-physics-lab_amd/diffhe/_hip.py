@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libdiffhe_hip.so"))
 
 _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_double
-ABI_VERSION = 6     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
+ABI_VERSION = 7     # DIFFHE_ABI_VERSION of include/diffhe_hip.h this binding was written against
 
 
 class MgLevel(C.Structure):
     """struct diffhe_mg_level (include/diffhe_hip.h)."""
     _fields_ = [("nx", _I), ("ny", _I), ("nd", _I), ("reserved", _I), ("vals", _P), ("is_bc", _P), ("vals32", _P),
-                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P), ("mask32", _P), ("offdiag16", _P), ("offdiag_scale", _D)]
+                ("dense_inv", _P), ("shift", _P), ("rdiag32", _P), ("mask32", _P), ("offdiag16", _P), ("offdiag_scales", _P)]
 
 
 _LV = C.POINTER(MgLevel)
@@ -70,7 +70,8 @@ SIGNATURES = {
     "diffhe_lattice_bilinear": (_I, [_LV, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_lattice_apply_shared": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "diffhe_lattice_pack_h16": (_I, [_LV, _I, _D, _P, _P, _P]),
+    "diffhe_lattice_pack_h16": (_I, [_LV, _I, _P, _P, _P, _P, _P]),
+    "diffhe_lattice_max_diag": (_I, [_LV, _I, _P, _P]),
     "diffhe_lattice_grad_kappa": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),

@@ -48,7 +48,12 @@ class TorchCollective:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         backend = dist.get_backend(group)
-        self.two_phase = backend == "nccl"      # gloo has no reduce_scatter_tensor: it keeps the single all-reduce
+        # Capability is decided HERE, once, identically on every rank (same backend, same torch build) -- never by
+        # catching a failed collective: after a genuine RCCL failure a second collective on the same communicator
+        # hangs, and a rank-local failure would leave the ranks in different collectives.  gloo has no
+        # reduce_scatter_tensor: it keeps the single all-reduce.
+        self.two_phase = (backend == "nccl" and hasattr(dist, "reduce_scatter_tensor")
+                          and hasattr(dist, "all_gather_into_tensor"))
         self.device_only = backend == "nccl"    # RCCL moves device memory only
 
     def all_reduce(self, flat: torch.Tensor) -> None:
@@ -67,13 +72,16 @@ def _default_collective(group):
     return TorchCollective(group)
 
 
-def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None, collective=None, stats: Optional[dict] = None) -> None:
+def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None, collective=None, stats: Optional[dict] = None,
+                        skip_single: bool = True) -> None:
     """In-place SUM all-reduce of several tensors (loss scalar + gradient) in as few messages as their sizes allow
-    (module docstring).  `stats`, if given, receives what was sent: bytes, number of collectives, path taken."""
+    (module docstring).  `stats`, if given, receives what was sent: bytes, number of collectives, path taken.
+    skip_single=False issues the collectives even in a group of one (the GPU test that runs every RCCL call of this
+    function on the one GPU of the test box).  Errors of a collective propagate: the process must exit non-zero."""
     coll = collective if collective is not None else _default_collective(group)
     if stats is not None:
         stats.update(bytes=0, collectives=0, path="none", staged_bytes=0)
-    if coll is None or coll.world == 1:
+    if coll is None or (coll.world == 1 and skip_single):
         return
     world = coll.world
     cuda = [t.device for t in tensors if t.is_cuda]
@@ -109,23 +117,14 @@ def allreduce_sum_fused(tensors: Sequence[torch.Tensor], group=None, collective=
                 if stats is not None:
                     stats["staged_bytes"] += buf.numel() * buf.element_size()
             mine = torch.empty(buf.numel() // world, dtype=buf.dtype, device=buf.device)
-            try:
-                coll.reduce_scatter(mine, buf)                 # this rank's 1/world of the sum
-                two_phase = True
-            except (RuntimeError, NotImplementedError, AttributeError) as exc:
-                # a backend / build without reduce_scatter_tensor: `buf` is untouched (the result went to `mine`), so
-                # the plain all-reduce is still exact.  Every rank raises alike (same call, same arguments).
-                coll.all_reduce(buf)
-                two_phase = False
-                paths.append(f"all_reduce(fallback: {type(exc).__name__})")
-            if two_phase:
-                coll.all_gather(buf, mine)                     # ... handed to everyone
-                paths.append("reduce_scatter+all_gather" + ("" if direct else "(staged)"))
+            coll.reduce_scatter(mine, buf)                     # this rank's 1/world of the sum
+            coll.all_gather(buf, mine)                         # ... handed to everyone
+            paths.append("reduce_scatter+all_gather" + ("" if direct else "(staged)"))
             if not direct:
                 t.copy_(buf[:n].reshape(t.shape))
             if stats is not None:
                 stats["bytes"] += n * t.element_size()
-                stats["collectives"] += 2 if two_phase else 1
+                stats["collectives"] += 2
     if stats is not None:
         stats["path"] = " | ".join(paths)
 

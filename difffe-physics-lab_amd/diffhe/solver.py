@@ -52,6 +52,12 @@ class SolveInfo:
     stop_rules: Optional[dict] = None
     adj_stop_rules: Optional[dict] = None
     tol_energy: float = 0.0     # the energy-norm tolerance in force for this call (0: residual rule alone)
+    # lattice path, fp32-stored V-cycle: where its coefficients come from -- "shared-fp32" (batch-shared matrix, scalar
+    # loads), "fp16-rowsum" (per-sample matrices: fp32 diagonal + scaled fp16 couplings), "fp32" (per-sample plain fp32
+    # copies: asked for, or the fallback when a sample's couplings span more than fp16 holds), "fp64" (no copies)
+    coeff_storage: str = ""
+    flags: int = 0              # lattice path: the `precond_fp32` word handed to diffhe_lattice_pcg_solve (include/diffhe_hip.h)
+    precision: str = ""         # what is stored / computed in which precision in THIS solve, derived from those flags
 
 
 def _resolve_device(device) -> torch.device:
@@ -273,12 +279,15 @@ class _Engine:
                 kl = kc
             v = torch.empty((lev.nd, lev.n, Bv), dtype=torch.float64, device=p.device)
             lf = torch.empty((lev.n, Bv), dtype=torch.float64, device=p.device) if li == 0 else None
-            if li == 0 and kl is not None and Bv != 1 and not self.ref_order:
-                # one matrix per sample (a kappa field per sample), default: entries sum_e kappa_e * fl(t_e / den_e) with
-                # the batch-shared quotients precomputed in the reference's rounding -- ONE rounding away from the
-                # reference's fl(fl(kappa_e t_e) / den_e) per contribution (a cond * eps effect in u, like the factored
-                # form) instead of twelve IEEE fp64 divisions per node and sample (10.3 -> 3 ms at 1024^2 x 256);
-                # operator="assembled" keeps the bit-identical order below
+            if li == 0 and mode == K_SAMPLE_ELEM and p.closed_boundary and not self.ref_order:
+                # one kappa FIELD per sample on a lattice closed by Dirichlet data, default: entries
+                # sum_e kappa_e * fl(t_e / den_e) with the batch-shared quotients precomputed in the reference's
+                # rounding -- ONE rounding away from the reference's fl(fl(kappa_e t_e) / den_e) per contribution (a
+                # cond * eps effect in u, like the factored form) instead of twelve IEEE fp64 divisions per node and
+                # sample (10.3 -> 3 ms at 1024^2 x 256).  NOT on lattices with Neumann parts (cond ~ 1e7 there: a last-bit
+                # difference of the entries shows as 4e-10 in u, which is why per-sample scalars are left unfactored on
+                # them, `closed_` in _solve_forward) -- they, per-sample SCALARS that are not factored, and
+                # operator="assembled" keep the bit-identical order below
                 self._lattice_rows(lev, lev.k0ref(), kl, kse, ksb, p.g, v, lf, Bv, st)
             elif li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
                 _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(lev.tnum), _hip.ptr(lev.den), _hip.ptr(kl), kse, ksb,
@@ -309,38 +318,42 @@ class _Engine:
                                                   7, Bv, st), "diffhe_ell_assemble_rows(lattice)")
 
     def pack_cycle_coeffs(self, vals, Bv):
-        """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, fp16 off-diagonals, scale) per level -- 8 instead of
-        12 B of coefficients per node and sample (3 diagonals); every row sum of the fp64 matrix is kept.  The
-        off-diagonals are stored divided by a power of two >= the largest diagonal entry of the fine level (one
-        reduction pass), so kappa of any magnitude stays inside the fp16 range."""
-        import math
+        """Per-sample matrices, fp32-stored V-cycle: (fp32 diagonals, fp16 off-diagonals, per-sample scales) per level --
+        8 instead of 12 B of coefficients per node and sample (3 diagonals); every row sum of the fp64 matrix is kept.
+        The off-diagonals of sample b are stored divided by a power of two >= that sample's largest free-row diagonal of
+        the fine level (one reduction pass), so kappa of any magnitude -- and samples of very different magnitudes in
+        one batch -- stay inside the fp16 range.  Contrast INSIDE a sample is what fp16 cannot hold: couplings below
+        2^-19 of the scale (fewer than 5 bits left; 0 from 2^-25 on, which would leave rows with a vanishing diagonal)
+        are reported by the packing kernel and the caller falls back to plain fp32 copies: returns (None, None, None)."""
         p, L = self.p, self.L
-        dmax = float(vals[0][0].amax())
-        if not (dmax > 0.0) or not math.isfinite(dmax):
-            return None, None, 0.0
-        scale = 2.0 ** math.ceil(math.log2(dmax))
+        st = _stream(p.device)
+        lev0 = (_hip.MgLevel * 1)()
+        lev0[0].nx, lev0[0].ny, lev0[0].nd = p.levels[0].nx, p.levels[0].ny, p.levels[0].nd
+        lev0[0].vals, lev0[0].is_bc = vals[0].data_ptr(), p.levels[0].is_bc.data_ptr()
+        dmax = torch.empty(Bv, dtype=torch.float64, device=p.device)
+        _hip.check(L.diffhe_lattice_max_diag(lev0, Bv, _hip.ptr(dmax), st), "diffhe_lattice_max_diag")
+        # power of two >= dmax (exact: frexp); samples without a positive finite diagonal (padding is kappa = 1) get 1
+        mant, expo = torch.frexp(dmax)
+        scales = torch.ldexp(torch.ones_like(dmax), expo - (mant == 0.5).to(expo.dtype))
+        ok = torch.isfinite(dmax) & (dmax > 0)
+        scales = torch.where(ok, scales, torch.ones_like(scales)).contiguous()
+        flags = torch.zeros(1, dtype=torch.int32, device=p.device)
         d32, o16 = [], []
         for lev, v in zip(p.levels, vals):
             one = (_hip.MgLevel * 1)()
             one[0].nx, one[0].ny, one[0].nd, one[0].vals = lev.nx, lev.ny, lev.nd, v.data_ptr()
-            # The strip kernels read one row + one column BEFORE a diagonal's first entry (column -1 of row 0: the value
-            # is multiplied by a zero window entry, but it must be mapped, finite memory): both arrays get a zeroed
-            # guard of (W + 1) rows of samples in front.
-            pad = (lev.nx + 2) * Bv
-            dbuf = torch.empty(pad + lev.n * Bv, dtype=torch.float32, device=p.device)
-            obuf = torch.empty(pad + (lev.nd - 1) * lev.n * Bv, dtype=torch.float16, device=p.device)
-            dbuf[:pad].zero_()
-            obuf[:pad].zero_()
-            d = dbuf[pad:].view(lev.n, Bv)
-            o = obuf[pad:].view(lev.nd - 1, lev.n, Bv)
-            _hip.check(L.diffhe_lattice_pack_h16(one, Bv, scale, _hip.ptr(d), _hip.ptr(o), _stream(p.device)),
+            d = torch.empty((lev.n, Bv), dtype=torch.float32, device=p.device)
+            o = torch.empty((lev.nd - 1, lev.n, Bv), dtype=torch.float16, device=p.device)
+            _hip.check(L.diffhe_lattice_pack_h16(one, Bv, _hip.ptr(scales), _hip.ptr(d), _hip.ptr(o), _hip.ptr(flags), st),
                        "diffhe_lattice_pack_h16")
             d32.append(d)
             o16.append(o)
-        return d32, o16, scale
+        if not bool(ok.all()) or int(flags[0]) != 0:
+            return None, None, None
+        return d32, o16, scales
 
     def lattice_levels(self, vals, vals32=None, dense=None, shift=None, rdiag32=None, off16=None):
-        off16, oscale = off16 if off16 is not None else (None, 0.0)
+        off16, oscales = off16 if off16 is not None else (None, None)
         """Level descriptors for the C ABI.  dense = (level index, inverse tensor): the hierarchy is cut at that
         level, whose solve becomes one dense product (diffhe_mg_level.dense_inv).  shift = per-level (n,) diagonal
         shifts of a factored operator (diffhe_mg_level.shift)."""
@@ -355,7 +368,7 @@ class _Engine:
             arr[i].rdiag32 = rdiag32[i].data_ptr() if rdiag32 is not None and rdiag32[i] is not None else None
             arr[i].offdiag16 = off16[i].data_ptr() if off16 is not None and off16[i] is not None else None
             arr[i].mask32 = lev.mask32().data_ptr() if (arr[i].rdiag32 or arr[i].offdiag16) else None
-            arr[i].offdiag_scale = oscale if arr[i].offdiag16 else 0.0
+            arr[i].offdiag_scales = oscales.data_ptr() if arr[i].offdiag16 else None
         return arr
 
     def lattice_pcg(self, vals, Bv, scale, rhs, Bp, mg, vals32=None, dense=None, x0=None, shift=None, rdiag32=None,
@@ -377,16 +390,15 @@ class _Engine:
         est = torch.empty(Bp, dtype=torch.float64, device=p.device)
         rule = torch.empty(Bp, dtype=torch.int32, device=p.device)
         st = status_buffer()
+        flags = (int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1) | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
+                 | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0)
+                 | (0 if int(mg.get("fused", 1)) else 64) | (0 if int(mg.get("dense_mfma", 1)) else 128)
+                 | (256 if (p.closed_boundary and p.regular_cells and p.dense_level() is not None
+                            and int(mg.get("cg_fp32_steplength", 1))) else 0))
+        self.last_flags = flags
         _hip.check(L.diffhe_lattice_pcg_solve(arr, nl, Bv, _hip.ptr(scale), _hip.ptr(rhs), _hip.ptr(x), Bp, self.tol,
                                               float(mg.get("tol_energy", 0.0) or 0.0),
-                                              min(self.max_iter, 500), len(omegas), mg["n_coarse"], om,
-                                              int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1)
-                                              | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
-                                              | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0)
-                                              | (0 if int(mg.get("fused", 1)) else 64)
-                                              | (0 if int(mg.get("dense_mfma", 1)) else 128)
-                                              | (256 if (p.closed_boundary and p.regular_cells and p.dense_level() is not None
-                                                         and int(mg.get("cg_fp32_steplength", 1))) else 0),
+                                              min(self.max_iter, 500), len(omegas), mg["n_coarse"], om, flags,
                                               _hip.ptr(work),
                                               _hip.ptr(relres), _hip.ptr(est), _hip.ptr(iters), _hip.ptr(rule),
                                               _hip.ptr(st), _stream(p.device)), "diffhe_lattice_pcg_solve")
@@ -486,6 +498,38 @@ class _Engine:
                                                  _hip.ptr(p.g), p.npe, p.m, B, Bp, _hip.ptr(dk), _stream(p.device)),
                    "diffhe_p1_grad_kappa_shared")
         return dk
+
+
+def _precision_text(flags: int, coeff_storage: str, Bv: int, Bp: int, fused_lib: int, recompute_ap: bool) -> str:
+    """Plain-words account of the precisions of one lattice solve, from the flag word actually passed to
+    diffhe_lattice_pcg_solve and the library's own switches (nothing here is a literal about 'the' configuration)."""
+    if not flags & 1:
+        return "fp64 throughout: every vector stored fp64, all arithmetic fp64"
+    spl2 = Bp % 128 == 0 and fused_lib == 2
+    packed = not flags & 64 and fused_lib != 0 and ((coeff_storage == "shared-fp32" and Bp % 64 == 0)
+                                                    or (coeff_storage == "fp16-rowsum" and spl2))
+    parts = ["iterate x, residual r, right-hand side, the updates x += alpha p and r -= alpha A p and EVERY reduction "
+             "(r.r, r.z, p.Ap accumulation, energy estimate): fp64",
+             "CG search directions p and all V-cycle (preconditioner) vectors: STORED fp32"]
+    if packed:
+        parts.append("V-cycle arithmetic: fp32 (" + ("packed, two samples per lane" if spl2 else "one sample per lane")
+                     + "; coefficients: "
+                     + {"shared-fp32": "batch-shared fp32 copies, scalar loads",
+                        "fp16-rowsum": "per-sample fp32 diagonal + scaled fp16 couplings, row sums kept"}[coeff_storage]
+                     + "); it is a preconditioner only")
+    else:
+        parts.append("V-cycle arithmetic: fp64 in registers on the fp32-stored vectors"
+                     + ("" if coeff_storage in ("", "fp64") else f" (coefficients: {coeff_storage})"))
+    if Bv == 1 and recompute_ap:
+        parts.append("A p is never stored: the residual update recomputes it in fp64 from the stored fp32 p")
+        if flags & 256 and Bp % 64 == 0 and coeff_storage == "shared-fp32":
+            parts.append("p.Ap: stencil in fp32 on the stored p, accumulated fp64 -- enters the STEP LENGTH alpha only "
+                         "(closed regular lattice); r = b - A x holds in fp64 whatever alpha is")
+        else:
+            parts.append("p.Ap: fp64 stencil")
+    else:
+        parts.append("A p: fp64, stored")
+    return "; ".join(parts)
 
 
 def _rule_counts(rule: torch.Tensor, B: int) -> dict:
@@ -660,8 +704,10 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
                 vals32, off16 = d32_, (o16_, osc_)
         if mg.get("fp32") and Bv != 1 and vals32 is None:
             vals32 = [v.float() for v in vals]
-        elif mg.get("fp32") and Bv == 1 and mg.get("strip2", 1) and Bp % 128 == 0 and shift is None:
+        elif mg.get("fp32") and Bv == 1 and mg.get("strip2", 1) and Bp % 64 == 0 and shift is None:
             vals32, rdiag32 = plan.shared_fp32(vals, cacheable=factored and kappa_free_unit)
+        info.coeff_storage = ("fp64" if not mg.get("fp32") else
+                              ("fp16-rowsum" if off16 is not None else "fp32") if Bv != 1 else "shared-fp32")
         dense = None
         if didx is not None:
             if didx == 0:
@@ -676,6 +722,9 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         if solver.warm_start and not bad:
             plan.warm_put(("u",) + wkey, x)           # never written again: the next solve starts from a copy
         info.stop_rules = _rule_counts(eng.last_rule, B) if info.path != "lattice-direct" else {}
+        info.flags = eng.last_flags
+        info.precision = _precision_text(eng.last_flags, info.coeff_storage, Bv, Bp, int(eng.L.diffhe_lattice_fused_passes()),
+                                         bool(eng.L.diffhe_lattice_recompute_ap()))
         info.tol_energy = float(mg.get("tol_energy", 0.0) or 0.0)
         ctx.dense = dense
         ctx.factored = factored

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIFFHE_ABI_VERSION 6
+#define DIFFHE_ABI_VERSION 7
 
 #define DIFFHE_OK 0
 #define DIFFHE_E_BADARG (-1)
@@ -262,13 +262,15 @@ typedef struct diffhe_mg_level {
                                   arithmetic, no division); needs mask32, Bp % 128 == 0 and no shift; NULL = the
                                   fp64-in-registers kernels */
   const float* mask32;         /* with rdiag32: (n) 0.0f on Dirichlet rows, 1.0f elsewhere (is_bc as scalar-loadable floats) */
-  const void* offdiag16;       /* optional, Bv == Bp only (ABI v6): fp16 off-diagonals (nd - 1, n, Bv) divided by
-                                  offdiag_scale; vals32 is then the (n, Bv) fp32 main diagonal adjusted to keep every row
-                                  sum of `vals` (diffhe_lattice_pack_h16 produces both): 4 + 2 (nd - 1) instead of 4 nd
-                                  bytes of coefficients per node and sample in the fp32-stored V-cycle.  Both arrays must
-                                  be preceded by (nx + 2) * Bv readable, zeroed elements (the strip kernels read one row
-                                  and one column before a diagonal's first entry) */
-  double offdiag_scale;        /* power of two >= the largest diagonal entry of `vals` (0 = offdiag16 unused) */
+  const void* offdiag16;       /* optional, Bv == Bp only (ABI v6): fp16 off-diagonals (nd - 1, n, Bv), those of sample b
+                                  divided by offdiag_scales[b]; vals32 is then the (n, Bv) fp32 main diagonal adjusted to
+                                  keep every row sum of `vals` (diffhe_lattice_pack_h16 produces both): 4 + 2 (nd - 1)
+                                  instead of 4 nd bytes of coefficients per node and sample in the fp32-stored V-cycle.
+                                  No kernel reads in front of (or behind) any array of this struct (ABI v7: the guard
+                                  elements v6 asked for in front of vals32 / offdiag16 are gone) */
+  const double* offdiag_scales; /* (Bv) device array, ABI v7: per-sample powers of two >= the sample's largest FREE-row
+                                  diagonal entry (diffhe_lattice_max_diag), so samples of any magnitude share a batch;
+                                  NULL = offdiag16 unused */
 } diffhe_mg_level;
 
 /* Batched CG preconditioned by one multigrid V(nu,nu) cycle (weighted Jacobi with the
@@ -377,11 +379,18 @@ int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, cons
 int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u, const double* g,
                               double* dk, int Bp, void* stream);
 /* Compact coefficient copies of a per-sample matrix for the fp32-stored V-cycle (diffhe_mg_level.vals32 / offdiag16):
- * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) fp16 of vals / offdiag_scale (a power of two >= max diagonal); the
- * diagonal absorbs the rounding differences of its row's couplings, so the row sums -- what the smooth error modes see
- * -- are those of `vals`. */
-int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, double offdiag_scale, float* diag32, void* offdiag16,
-                            void* stream);
+ * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) fp16 of vals / offdiag_scales[b] (per-sample powers of two >= the
+ * sample's max free-row diagonal, device array of Bv doubles); the diagonal absorbs the rounding differences of its row's
+ * couplings, so the row sums -- what the smooth error modes see -- are those of `vals`.
+ * flags (device int, may be NULL; the caller zeroes it): bit 0 is set when a non-zero coupling is smaller than 2^-19 of
+ * its sample's scale -- fp16 keeps fewer than 5 bits there and flushes to 0 from 2^-25 on, which would leave rows with a
+ * vanishing diagonal: the packed copies of a matrix with that much contrast INSIDE a sample must not be used (plain fp32
+ * copies in vals32 have no such limit).  ABI v7. */
+int diffhe_lattice_pack_h16(const diffhe_mg_level* level, int Bv, const double* offdiag_scales, float* diag32,
+                            void* offdiag16, int* flags, void* stream);
+/* out[b] = max over the FREE rows (is_bc == 0; identity rows carry 1.0 whatever kappa is) of the main diagonal of sample
+ * b's level matrix, Bv doubles (zeroed inside).  ABI v7. */
+int diffhe_lattice_max_diag(const diffhe_mg_level* level, int Bv, double* out, void* stream);
 /* kappa of the coarse triangulation, arrays (m, Bv); sx, sy in {1, 2} = coarsening factor per direction.
  * Full coarsening: mean of the 4 children of each coarse triangle; semi: mean over the 2 covered fine cells. */
 int diffhe_lattice_restrict_kappa(const double* kappa_fine, double* kappa_coarse, int nx_coarse, int ny_coarse,

@@ -378,3 +378,81 @@ def test_bench_two_ranks_on_the_hip_path():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["value"] > 0
     assert res["config"]["solver"] == "lattice-mgpcg" and res["solver_iters"]["not_converged"] == 0
     assert res["metric"].startswith("FEM solves/sec (fwd+adjoint), 2D P1 Poisson 256^2 mesh, batch=64")
+
+
+# --- RCCL itself, once, on the one GPU of the test box ------------------------------------------------------------------------
+_NCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "difffe-physics-lab_amd"))
+import torch
+import torch.distributed as dist
+from diffhe.distributed import TorchCollective, allreduce_sum_fused
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+coll = TorchCollective()
+assert coll.world == 1 and coll.two_phase and coll.device_only, (coll.world, coll.two_phase, coll.device_only)
+gen = torch.Generator(device=dev).manual_seed(0)
+for n in (2 * 1024 * 1024 + 4096, 2 * 1024 * 1024, 1 << 17, 131075, 1):      # 16.8 MB (config 4's gradient), 1 MiB, odd, 8 B
+    g = torch.randn(n, generator=gen, dtype=torch.float64, device=dev)
+    want = g.clone()
+    mine = torch.empty_like(g)
+    coll.reduce_scatter(mine, g)                   # world 1: this rank's "1 / world" is everything
+    back = torch.full_like(g, float("nan"))
+    coll.all_gather(back, mine)
+    flat = g.clone()
+    coll.all_reduce(flat)
+    torch.cuda.synchronize()
+    assert torch.equal(mine, want) and torch.equal(back, want) and torch.equal(flat, want), n
+# the whole of allreduce_sum_fused on RCCL: the in-place two-phase branch, the staged one (a strided gradient) and the
+# fused small message, issued for real (skip_single=False) in a group of one
+m = 2 * 1024 * 1024
+grad = torch.randn(m, generator=gen, dtype=torch.float64, device=dev)
+base = torch.randn(1 << 17, 2, generator=gen, dtype=torch.float64, device=dev)
+strided = base[:, 0]
+loss = torch.tensor([1.25], dtype=torch.float64, device=dev)
+w_grad, w_str, ptr = grad.clone(), strided.clone(), grad.data_ptr()
+stats = {}
+allreduce_sum_fused([loss, grad, strided], collective=coll, stats=stats, skip_single=False)
+torch.cuda.synchronize()
+assert grad.data_ptr() == ptr and torch.equal(grad, w_grad) and torch.equal(strided, w_str) and float(loss) == 1.25
+assert stats["path"] == "all_reduce | reduce_scatter+all_gather | reduce_scatter+all_gather(staged)", stats
+assert stats["collectives"] == 5 and stats["bytes"] == 8 * m + 8 * (1 << 17) + 8, stats
+dist.destroy_process_group()
+print("NCCL_WORLD1_OK", stats["path"])
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_collectives_run_for_real_in_a_world_of_one():
+    """The three RCCL calls of the gradient exchange -- reduce_scatter_tensor, all_gather_into_tensor, all_reduce on fp64
+    device buffers -- had never executed anywhere (the test box has one GPU, the CPU tests use gloo / an in-process fake).
+    A world-size-1 `nccl` process group on cuda:0, in a FRESH child process (started before anything here touches RCCL),
+    runs them on the sizes of the real exchange: 16.8 MB, a length that needs staging, 8 bytes; and `allreduce_sum_fused`
+    end to end.  Capability is decided at TorchCollective construction (two_phase), never by catching a failed collective."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", _NCCL_WORLD1, ROOT], capture_output=True, text=True, timeout=500, env=env)
+    assert out.returncode == 0 and "NCCL_WORLD1_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+def test_rank_affinity_slices_follow_the_gpu_numa_nodes():
+    """bench.py pins every rank to the cores next to its GPU (pure function; the sysfs readers never raise)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    allowed = set(range(128))
+    node_cpus = {0: set(range(0, 64)), 1: set(range(64, 128))}
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    slices = [bench.rank_cpu_slice(allowed, 8, r, numa, node_cpus) for r in range(8)]
+    assert all(len(s_) == 16 for s_ in slices)
+    assert slices[0] == list(range(0, 16)) and slices[3] == list(range(48, 64)) and slices[4] == list(range(64, 80))
+    assert len(set().union(*map(set, slices))) == 128                       # disjoint, everything used
+    # a restricted affinity mask (a container's cpuset) is respected; unknown topology: even contiguous slices
+    assert bench.rank_cpu_slice(set(range(8, 24)), 2, 1, [0, 0], {0: set(range(64))}) == list(range(16, 24))
+    assert bench.rank_cpu_slice(set(range(16)), 4, 2) == [8, 9, 10, 11]
+    assert bench.rank_cpu_slice(set(range(16)), 4, 2, [-1, -1, -1, -1], {}) == [8, 9, 10, 11]
+    assert bench.rank_cpu_slice({0, 1}, 8, 5) == [0, 1]                     # fewer cores than ranks: no pinning
+    assert isinstance(bench.gpu_numa_nodes(), list)
+    assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}

@@ -506,6 +506,8 @@ def _partly_neumann(nx, ny):
     ("odd sizes 333 x 207 (edge strips), non-zero Dirichlet data", FEMesh.rectangle(333, 207, bc_value=0.7), "sample"),
     ("skewed lattice (4 diagonals)", _skewed(272, 232), "sample"),
     ("partly Neumann boundary (assembled scalar-kappa operator, shared)", _partly_neumann(240, 224), "scalar"),
+    ("partly Neumann boundary, one scalar PER SAMPLE (unfactored: per-sample matrices in the reference's operation order)",
+     _partly_neumann(232, 216), "sample"),
     ("one per-element field shared by the batch", FEMesh.rectangle(288, 264), "field"),
     ("one field PER SAMPLE (per-sample matrices: fused passes on compact per-lane coefficients)", FEMesh.rectangle(272, 240, bc_value=0.3), "fields"),
     ("one field per sample, skewed lattice (4 diagonals)", _skewed(240, 216, seed=2), "fields"),
@@ -640,3 +642,100 @@ def test_general_path_at_512_takes_at_most_45_iterations():
     with torch.no_grad():
         u2 = lat(f)
     assert float((u - u2).abs().max() / u2.abs().max()) < 1e-10
+
+
+# ---- fp16 coefficient copies: magnitudes across the batch, contrast inside a sample ---------------------------
+def test_per_sample_fields_of_very_different_magnitudes_share_a_batch():
+    """kappa_b(x) = c_b exp(0.3 randn) with c_b spread over 1e-6 .. 1e6 across the batch.  The fp16 couplings of the
+    V-cycle are stored relative to a PER-SAMPLE power of two (the sample's largest free-row diagonal; the identity rows
+    of Dirichlet nodes, 1.0 whatever kappa is, do not count), so every sample keeps 11 bits: compact coefficients stay in
+    use, iteration counts are those of an all-O(1) batch, and the answers meet the oracle."""
+    mesh = FEMesh.rectangle(256, 240, bc_value=0.25)
+    B, n, m = 128, mesh.n_nodes, mesh.n_elements
+    gen = torch.Generator().manual_seed(21)
+    base = torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))
+    mag = 10.0 ** (12.0 * torch.rand(B, generator=gen, dtype=T64) - 6.0)
+    mag[0], mag[-1] = 1e-6, 1e6
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    ref = _run(mesh, base, f)
+    new = _run(mesh, base * mag[:, None], f)
+    assert new[3].coeff_storage == "fp16-rowsum" and ref[3].coeff_storage == "fp16-rowsum"
+    assert new[3].not_converged == 0 and bool(torch.isfinite(new[0]).all()) and bool(torch.isfinite(new[1]).all())
+    assert new[3].iterations <= ref[3].iterations + 1 and new[3].adj_iterations <= ref[3].adj_iterations + 1
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B // 2, B - 1):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, (base[b] * mag[b]).numpy(),
+                                            f[b].numpy(), lambda u_: 2 * u_, sparse=True, refine=2)
+        assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U
+        assert rel_err(new[1][b].cpu().numpy(), dk) < RTOL_GRAD
+        assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD
+
+
+def test_contrast_inside_a_sample_beyond_fp16_falls_back_to_fp32_copies():
+    """A conductivity jump of 3e-7 inside every sample (left half O(1), right half 3e-7, log-normal noise on top): couplings
+    of the weak half would land in fp16 subnormals / flush to 0 relative to the sample's scale, and with the row-sum rule an
+    interior row of that half would get a vanishing diagonal (1 / 0 in the smoother).  The packing kernel reports it and the
+    solve runs on plain fp32 copies instead: converged, finite, oracle-accurate."""
+    mesh = FEMesh.rectangle(256, 224)
+    B, n, m = 128, mesh.n_nodes, mesh.n_elements
+    gen = torch.Generator().manual_seed(22)
+    cx = mesh.nodes[mesh.elements].mean(dim=1)[:, 0]                 # element centroids
+    jump = torch.where(cx < 0.5, torch.ones(m, dtype=T64), torch.full((m,), 3e-7, dtype=T64))
+    kappa = jump[None, :] * torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    u, gk, gf, info = _run(mesh, kappa, f)
+    assert info.coeff_storage == "fp32"
+    assert info.not_converged == 0 and all(bool(torch.isfinite(t).all()) for t in (u, gk, gf))
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B - 1):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, kappa[b].numpy(), f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=2)
+        eu, ek, ef = rel_err(u[b].cpu().numpy(), uo), rel_err(gk[b].cpu().numpy(), dk), rel_err(gf[b].cpu().numpy(), df)
+        print(f"jump 3e-7, sample {b}: u {eu:.1e} dkappa {ek:.1e} df {ef:.1e}, iterations {info.iterations}+{info.adj_iterations}")
+        assert eu < 1e-9 and ek < 1e-9 and ef < 1e-9     # cond ~ 1e7 x the uniform mesh's: cond * eps, both codes
+
+
+# ---- no load precedes any coefficient array (ABI v7; the fault of gpurun_out/r3i) -----------------------------------------
+@pytest.mark.parametrize("B", [64, 128])
+def test_no_kernel_reads_in_front_of_the_coefficient_arrays(B):
+    """Every coefficient array handed to diffhe_lattice_pcg_solve -- fp64 values, fp32 diagonal, fp16 couplings, and for a
+    shared matrix the fp32 copy, reciprocal diagonal and mask -- is placed directly behind a NaN-filled region of one
+    allocation.  ABI v6 kernels read one element in front of a diagonal (times a zero window value: 0 x NaN = NaN, or a
+    fault when the array starts an allocation); v7 kernels must not: results bitwise equal to the plain run.
+    B = 64: one-sample strip kernels on per-lane fp16 couplings (the faulting instantiation); 128: fused passes."""
+    from diffhe.solver import _Engine, K_SAMPLE_ELEM, K_SAMPLE
+    from diffhe.plan import padded_batch
+    mesh = FEMesh.rectangle(224, 200)
+    plan = get_plan(mesh, torch.device(DEV))
+    n, m = mesh.n_nodes, mesh.n_elements
+    gen = torch.Generator().manual_seed(5)
+    mg = dict(nu=2, n_coarse=8, omega=0.8, omegas=None, fp32=1, fmg=1, floor=1, tol_energy=1e-11)
+
+    def behind_nan(t):
+        pad = 4096
+        raw = torch.empty(pad + t.numel() * t.element_size(), dtype=torch.uint8, device=DEV)
+        raw[:pad] = 0xFF                                  # all-ones bytes: NaN in fp16, fp32 and fp64
+        out = raw[pad:].view(t.dtype).view(t.shape)
+        out.copy_(t)
+        return out
+
+    for mode, kappa in ((K_SAMPLE_ELEM, torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))),
+                        (K_SAMPLE, 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64))):
+        eng = _Engine(plan, 1e-13, 200, 25, "gather")
+        Bp = padded_batch(B)
+        vals, Bv, scale, lift, _ = eng.lattice_assemble(kappa.to(DEV), mode, B, Bp, factor=True)
+        rhs = torch.randn(n, Bp, generator=torch.Generator(device=DEV).manual_seed(1), dtype=T64, device=DEV)
+        rhs[plan.bc_index()] = 0.0
+        if Bv != 1:
+            d32, o16, osc = eng.pack_cycle_coeffs(vals, Bv)
+            assert d32 is not None
+            plain = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, d32, None, off16=(o16, osc))
+            moved = eng.lattice_pcg([behind_nan(v) for v in vals], Bv, scale, rhs, Bp, mg, [behind_nan(d) for d in d32], None,
+                                    off16=([behind_nan(o) for o in o16], behind_nan(osc)))
+        else:
+            v32, rd32 = plan.shared_fp32(vals, cacheable=False)
+            plain = eng.lattice_pcg(vals, Bv, scale, rhs, Bp, mg, v32, None, rdiag32=rd32)
+            moved = eng.lattice_pcg([behind_nan(v) for v in vals], Bv, scale, rhs, Bp, mg, [behind_nan(v) for v in v32], None,
+                                    rdiag32=[behind_nan(r) for r in rd32])
+        assert plain[2] == 0 and moved[2] == 0 and bool(torch.isfinite(moved[0]).all())
+        assert torch.equal(plain[0], moved[0]) and plain[1] == moved[1]

@@ -39,13 +39,14 @@ RULES = [
     ("pcg_finish_kernel", "x += sum_j alpha_j p_j + V(r) (end of a solve; 5 directions)", 5.0),
     ("mg_dense_solve_kernel", "dense coarse solve (33^2 level)", 0.0),
     ("mg_dense_mfma_kernel", "dense coarse solve (33^2 level) on MFMA", 0.0),
-    ("pcg_init_kernel", "b.b and fp32 copy of b (x, r are set after the full-multigrid start)", 1.5),
+    ("pcg_init_kernel", "b.b (x, r are set after the full-multigrid start: b is read, nothing is written)", 1.0),
     ("to_node_major_kernel", "(B,n) -> (n,Bp)", 2.0),
     ("to_sample_major_kernel", "(n,Bp) -> (B,n)", 2.0),
     ("dia_shared_apply_kernel", "F = M f - lift", 2.0),
     ("dia_strip_kernel<double, double, double, 0, 0, 4", "F = M f - lift (strip kernel)", 2.0),
     ("dia_strip_kernel<double, double, double, 0, 0, 3", "dL/dkappa bilinear form lambda^T K_1 u", 2.0),
-    ("pcg_setx_kernel", "x = x0 (fp32 -> fp64)", 1.5),
+    ("pcg_cvt_kernel", "fp32 copy of rs * b", 1.5),
+    ("pcg_setx_kernel", "x = x0 + e0 (two fp32 vectors -> fp64)", 2.0),
     ("lattice_grad_kappa_kernel", "per-element gradient, lattice strip pass", 4.0),
     ("grad_kappa_shared_kernel", "gradient of a shared kappa field (summed over the batch)", 2.0),
 ]
