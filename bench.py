@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "difffe-physics-lab_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = "r03_pmc_traffic.json"   # profiles/: rocprofv3 --pmc passes over this command, reduced by tools/pmc_reduce.py
+PMC_PROFILE = "r04_pmc_traffic.json"   # profiles/: rocprofv3 --pmc passes over this command, reduced by tools/pmc_reduce.py
 
 
 def parse(argv=None):
@@ -52,6 +52,7 @@ def parse(argv=None):
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--variant-reps", type=int, default=3, help="repetitions per variant (the median is reported)")
     ap.add_argument("--tol", type=float, default=None, help="override the solver's relative residual tolerance")
+    ap.add_argument("--max-iter", type=int, default=None, help="cap the CG iterations (development: kernel experiments)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="rehearsal only: put every rank on this device index (needs --backend gloo)")
@@ -218,6 +219,8 @@ def main():
     n, m = mesh.n_nodes, mesh.n_elements
     node = args.layout == "node"
     tol_kw = {"tol": args.tol} if args.tol else {}
+    if args.max_iter:
+        tol_kw["max_iter"] = args.max_iter
     t_plan = time.perf_counter()
     if world > 1:           # rank 0 builds the plan (and fills the node-level cache) first, the others map it
         os.makedirs(os.environ["DIFFHE_PLAN_CACHE"], exist_ok=True)
@@ -651,7 +654,7 @@ def variant_config2(args, torch, L, _hip, ctypes, dev, timed):
 
 
 def _lattice_variant_roofline(L, ctypes, n, Bp, f32):
-    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0,
+    rows = kernel_table(read_kprof(L, ctypes), n, Bp, f32, fused=bool(L.diffhe_lattice_fused_passes()) and Bp % 64 == 0,
                         rupd=bool(L.diffhe_lattice_recompute_ap()) and f32)
     if not rows:
         return None
@@ -803,8 +806,9 @@ KERNEL_NAME_RUPD = "residual update with A p recomputed from the stored p: r -= 
 KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, false, 4, 5>"
 
 
-KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true>",
-                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true, false>", KERNEL_SYMBOLS_FP32[5]]
+KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true, 4, 4>",
+                        KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true, false, 4, 4>",
+                        KERNEL_SYMBOLS_FP32[5]]
 
 
 def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, prof_n, kprof=()):
@@ -816,7 +820,7 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     if not (path == "lattice-mgpcg" and args.kappa == "sample" and Bp >= 64 and N >= 191 and len(kprof) == 6):
         return None
     f32 = bool(solver.mg.get("fp32"))
-    fused = bool(L.diffhe_lattice_fused_passes()) and Bp % 128 == 0 and bool(solver.mg.get("fused", 1))
+    fused = bool(L.diffhe_lattice_fused_passes()) and Bp % 64 == 0 and bool(solver.mg.get("fused", 1))
     rupd = bool(L.diffhe_lattice_recompute_ap()) and f32
     table = kernel_table(kprof, n, Bp, f32, fused, rupd)
     if not table:
@@ -824,7 +828,7 @@ def roofline(args, torch, L, _hip, solver, plan, kappa, n, B, N, dev, prof_ms, p
     symbols = list(KERNEL_SYMBOLS_FUSED if fused else KERNEL_SYMBOLS_FP32)
     if rupd:
         symbols[1] = KERNEL_SYMBOL_RUPD
-        if fused:      # two samples per lane (multiples of 128): the packed-fp32 CG step
+        if fused:      # the fp32 CG step (packed, two samples per lane, for multiples of 128)
             symbols[0] = KERNEL_SYMBOL_CGSTEP2
     have = [sy for sy, (ms_, n_) in zip(symbols, kprof) if n_ > 0]
     traffic, src = pmc_traffic(have, 8 * n * Bp) if f32 else ({}, "fp64 storage: no PMC profile")

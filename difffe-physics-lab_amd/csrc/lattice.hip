@@ -921,6 +921,10 @@ __device__ __forceinline__ double block_sum_waves(double v, double* lds /* >= NW
   return s;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+struct Acc { double v[4] = {0.0, 0.0, 0.0, 0.0}; };   // per-sample dot-product accumulators of one lane (kSpl used)
+
 template <typename VT> struct VLane;
 template <> struct VLane<float> {
   static constexpr int kSpl = 1;
@@ -929,7 +933,7 @@ template <> struct VLane<float> {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
   }
   static __device__ __forceinline__ float from_scale(const double* __restrict__ s, unsigned lb) { return s ? (float)s[lb] : 1.0f; }
-  static __device__ __forceinline__ void dot(double& s0, double& s1, float a, float b) { s0 += (double)(a * b); (void)s1; }
+  static __device__ __forceinline__ void dot(Acc& s, float a, float b) { s.v[0] += (double)(a * b); }
 };
 template <> struct VLane<v2f> {
   static constexpr int kSpl = 2;
@@ -938,12 +942,50 @@ template <> struct VLane<v2f> {
   static __device__ __forceinline__ v2f from_scale(const double* __restrict__ s, unsigned lb) {
     return s ? v2f{(float)s[lb], (float)s[lb + 1]} : v2f{1.0f, 1.0f};
   }
-  static __device__ __forceinline__ void dot(double& s0, double& s1, v2f a, v2f b) {
+  static __device__ __forceinline__ void dot(Acc& s, v2f a, v2f b) {
     const v2f p = a * b;
-    s0 += (double)p.x;
-    s1 += (double)p.y;
+    s.v[0] += (double)p.x;
+    s.v[1] += (double)p.y;
   }
 };
+// FOUR samples per lane, 256 per wave: one 16-byte access per lane and node -- half the vector-memory instructions per
+// byte of the two-sample form (the fused passes are bound by the NUMBER of those instructions),
+// twice the registers per lane (2 waves per SIMD instead of 4: the same bytes in flight per SIMD).
+template <> struct VLane<v4f> {
+  static constexpr int kSpl = 4;
+  static __device__ __forceinline__ v4f zero() { return v4f{0.0f, 0.0f, 0.0f, 0.0f}; }
+  static __device__ __forceinline__ v4f ld(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ v4f from_scale(const double* __restrict__ s, unsigned lb) {
+    return s ? v4f{(float)s[lb], (float)s[lb + 1], (float)s[lb + 2], (float)s[lb + 3]} : v4f{1.0f, 1.0f, 1.0f, 1.0f};
+  }
+  static __device__ __forceinline__ void dot(Acc& s, v4f a, v4f b) {
+    const v4f p = a * b;
+    s.v[0] += (double)p.x;
+    s.v[1] += (double)p.y;
+    s.v[2] += (double)p.z;
+    s.v[3] += (double)p.w;
+  }
+};
+
+// A vector stream of the fused kernels: buffer-resource addressing (raw_buffer_load, 32-bit per-lane offset + uniform
+// SGPR row offset) or, with -DDIFFHE_FLAT_LD=1, global loads off a wave-uniform 64-bit base (SGPR pair, the row offset
+// added by the scalar unit) + the 32-bit per-lane offset (the form strip_body uses).  A/B switch of round 4: the PMC
+// counters show the texture-addresser FIFOs full 28-35 % of the time in the buffer-load kernels and never in strip_body's.
+#ifndef DIFFHE_FLAT_LD
+#define DIFFHE_FLAT_LD 0
+#endif
+struct Src {
+  rsrc_t r;
+  const char* p;
+};
+__device__ __forceinline__ Src make_src(const void* p) { return Src{make_rsrc(p), (const char*)p}; }
+template <typename VT>
+__device__ __forceinline__ VT ldsrc(const Src& s, unsigned voff, unsigned soff) {
+  if constexpr (DIFFHE_FLAT_LD != 0) return *(const VT*)((s.p + (size_t)soff) + (size_t)voff);
+  else return VLane<VT>::ld(s.r, voff, soff);
+}
 
 // Where the matrix coefficients of the fused passes come from.
 //   SHARED: batch-shared fp32 copies + reciprocal diagonal, wave-uniform scalar loads (values are plain floats);
@@ -1066,7 +1108,7 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
   }
   // base: element (r0 - 2, c0w - 4): every offset below is non-negative
   const i64 tile0 = ((i64)(r0 - 2) * W + (c0w - 4)) * Bp;
-  const rsrc_t rr = make_rsrc(rhs + tile0);
+  const Src rr = make_src(rhs + tile0);
   const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;
   const float inv_w0 = 1.0f / w0;
 
@@ -1081,7 +1123,7 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
     const i64 rb = (i64)R * W + (c0w - 2);
 #pragma unroll
     for (int j = 0; j < N1; ++j) {
-      const VT v = VLane<VT>::ld(rr, off1[j], sx);
+      const VT v = ldsrc<VT>(rr, off1[j], sx);
       i64 i = rb + j;
       if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
       const typename CF::T dv = SHARED ? typename CF::T{} : cf.d(i);
@@ -1134,7 +1176,7 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
       const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
 #pragma unroll
       for (int j = 0; j < N1; ++j) {
-        const VT v = VLane<VT>::ld(rr, off1[j], sx);
+        const VT v = ldsrc<VT>(rr, off1[j], sx);
         dst[j] = ok1[j] ? (v * ib) * (w0 * (1.0f / D[j])) : Z;
       }
     };
@@ -1319,11 +1361,12 @@ __device__ __forceinline__ void fused_pre_body(const Level& L, VT ib, VT sb, con
   }
 }
 
-// NW = waves per block: a block owns NW * CW adjacent coarse columns.  What reaches the fabric is each BLOCK's footprint
-// once (PMC: neighbouring blocks do not share their halo columns in L2), so wider blocks cut the column halo: 4 waves read
-// (16 + 4) / 16 of x, 8 waves (32 + 4) / 32, 16 waves (64 + 4) / 64.
-template <typename VT, int ND, int CW, bool SHARED, int NW = 4>
-__global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_pre_kernel(Level L, const double* __restrict__ scale,
+// NW = waves per block (a block owns NW * CW adjacent coarse columns).  Round 4 measured 8 and 16 against 4 on the
+// 1024^2 x 256 bench (gpurun_out/r4c): WIDER blocks read MORE from the fabric, not less (POST 1.56 -> 1.65 / 1.66 read
+// passes: the waves of a larger block drift apart and miss each other's halo lines) and run slower (PRE 0.708 -> 0.740 /
+// 0.818 ms, POST 1.000 -> 0.978 / 1.101 ms, step 81.7 -> 82.6 / 86.6 ms).  4 stays; the parameter documents the experiment.
+template <typename VT, int ND, int CW, bool SHARED, int NW = 4, int MW = (SHARED ? 4 : 1)>
+__global__ __launch_bounds__(64 * NW, MW) void fused_pre_kernel(Level L, const double* __restrict__ scale,
                                                          const float* __restrict__ rhs, float* __restrict__ x2out,
                                                          float* __restrict__ crhs, float w0, float w1, int cW,
                                                          const unsigned char* __restrict__ cbc, int Bp, int ncb, int TR) {
@@ -1356,7 +1399,7 @@ template <typename VT, int ND, int RW, bool EDGE, bool DOT, bool SHARED, bool XZ
 __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const float* __restrict__ xin,
                                                 const float* __restrict__ rhs, const float* __restrict__ ec,
                                                 float* __restrict__ zout, float wA, float wB, int cW, int Bp, unsigned lb,
-                                                int c0w, int r0, int r1, double& s0, double& s1) {
+                                                int c0w, int r0, int r1, Acc& acc) {
   constexpr int N1 = RW + 4, N2 = RW + 2;    // x' window: columns c0w - 2 + j; x3 window: c0w - 1 + j
   constexpr int NCE = RW / 2 + 3;            // coarse columns (c0w - 2) / 2 .. (c0w + RW + 1 + 1) / 2
   const int W = L.W, nyp = L.ny + 1;
@@ -1384,10 +1427,10 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     offc[j] = 4u * ((unsigned)cj * (unsigned)Bp + lb);
   }
   const i64 tile0 = ((i64)(r0 - 2) * W + (c0w - 4)) * Bp;
-  const rsrc_t rx = make_rsrc(XZ ? rhs + tile0 : xin + tile0);   // XZ: x = 0, never loaded
-  const rsrc_t rr = make_rsrc(rhs + tile0);
+  const Src rx = make_src(XZ ? rhs + tile0 : xin + tile0);   // XZ: x = 0, never loaded
+  const Src rr = make_src(rhs + tile0);
   const int cr0 = (r0 - 2 > 0 ? r0 - 2 : 0) >> 1;
-  const rsrc_t rc = make_rsrc(ec + (i64)cr0 * cW * Bp);
+  const Src rc = make_src(ec + (i64)cr0 * cW * Bp);
   const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp, rowCB = 4u * (unsigned)cW * (unsigned)Bp;
 
   // x' = x + mask (P e) on grid row R
@@ -1399,11 +1442,14 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     }
     const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
     const unsigned sc = (unsigned)((R >> 1) - cr0) * rowCB;
+    // (Keeping the coarse row in registers between fine rows -- it is loaded three times, 7.5 of a row's 23 loads -- was
+    // built and measured in round 4: + 10 live VGPRs spill (100 B of scratch at the 128-VGPR cap of the shared form, 16-100 B
+    // at the 168 cap of the per-sample one): POST 1.000 -> 1.034 ms, per-element-field step 213.5 -> 232.0 ms; gpurun_out/r4i.)
     VT ce[NCE], ce2[NCE];
 #pragma unroll
     for (int j = 0; j < NCE; ++j) {
-      ce[j] = VLane<VT>::ld(rc, offc[j], sc);
-      ce2[j] = (R & 1) ? VLane<VT>::ld(rc, offc[j], sc + rowCB) : Z;
+      ce[j] = ldsrc<VT>(rc, offc[j], sc);
+      ce2[j] = (R & 1) ? ldsrc<VT>(rc, offc[j], sc + rowCB) : Z;
     }
     const i64 rb = (i64)R * W + (c0w - 2);
 #pragma unroll
@@ -1415,7 +1461,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
         corr = (R & 1) ? 0.5f * (ce[(j + 1) / 2] + ce2[(j - 1) / 2]) : 0.5f * (ce[(j - 1) / 2] + ce[(j + 1) / 2]);
       i64 i = rb + j;
       if (EDGE) i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-      const VT v = XZ ? L.mk32[i] * corr : VLane<VT>::ld(rx, off1[j], sx) + L.mk32[i] * corr;
+      const VT v = XZ ? L.mk32[i] * corr : ldsrc<VT>(rx, off1[j], sx) + L.mk32[i] * corr;
       dst[j] = ok1[j] ? v : Z;
     }
   };
@@ -1428,7 +1474,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     }
     const unsigned sx = (unsigned)(R - (r0 - 2)) * rowB;
 #pragma unroll
-    for (int j = 0; j < N2; ++j) dst[j] = ok1[j + 1] ? VLane<VT>::ld(rr, off1[j + 1], sx) * ib : Z;
+    for (int j = 0; j < N2; ++j) dst[j] = ok1[j + 1] ? ldsrc<VT>(rr, off1[j + 1], sx) * ib : Z;
   };
   // x3 on grid row R (window N2) from x' rows R - 1, R, R + 1 and bu row R
   auto x3_row = [&](int R, const VT* am, const VT* ac, const VT* ap, const VT* bu, VT* dst) {
@@ -1526,7 +1572,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
         if (!EDGE || c0w + k < W) {
           const VT z = b1[k + 1] + (wB * rd) * (u1[k + 1] - kx);
           *(VT*)(pz + (i64)k * Bp + lb) = z;
-          if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);
+          if (DOT) VLane<VT>::dot(acc, u1[k + 1], z);
         }
       });
       pz += (i64)W * Bp;
@@ -1558,7 +1604,7 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
       if (!EDGE || c0w + k < W) {
         const VT z = b1[k + 1] + (wB * rd) * (u1[k + 1] - kx);
         *(VT*)(pz + (i64)k * Bp + lb) = z;
-        if (DOT) VLane<VT>::dot(s0, s1, u1[k + 1], z);     // (r / s_b) . z; times s_b after the loop
+        if (DOT) VLane<VT>::dot(acc, u1[k + 1], z);     // (r / s_b) . z; times s_b after the loop
       }
     });
     pz += (i64)W * Bp;
@@ -1569,8 +1615,8 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
 
 // XZ: the operand is P e alone (x = 0 is not read): two sweeps from a prolonged initial guess, the first stage of a
 // full-multigrid level (vcycle with `guess`)
-template <typename VT, int ND, int RW, bool DOT, bool SHARED, bool XZ = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_post_kernel(Level L, const double* __restrict__ scale,
+template <typename VT, int ND, int RW, bool DOT, bool SHARED, bool XZ = false, int NW = 4, int MW = (SHARED ? 4 : 1)>
+__global__ __launch_bounds__(64 * NW, MW) void fused_post_kernel(Level L, const double* __restrict__ scale,
                                                           const float* __restrict__ xin, const float* __restrict__ rhs,
                                                           const float* __restrict__ ec, float* __restrict__ zout, float wA,
                                                           float wB, int cW, double* __restrict__ part, int Bp, int ncb,
@@ -1589,22 +1635,20 @@ __global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_post_kernel(Lev
   const bool active = c0w < L.W && r0 < r1;
   const VT sb = VLane<VT>::from_scale(scale, lb);
   const VT ib = 1.0f / sb;
-  double s0 = 0.0, s1 = 0.0;
+  Acc acc;
   if (active) {
     const bool edge = c0w - 2 < 0 || c0w + RW + 1 > L.W - 1 || r0 - 2 < 0 || r1 + 1 > nyp - 1;
     if (edge)
-      fused_post_body<VT, ND, RW, true, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+      fused_post_body<VT, ND, RW, true, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, acc);
     else
-      fused_post_body<VT, ND, RW, false, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, s0, s1);
+      fused_post_body<VT, ND, RW, false, DOT, SHARED, XZ>(L, ib, xin, rhs, ec, zout, wA, wB, cW, Bp, lb, c0w, r0, r1, acc);
   }
   if (DOT) {
-    const double f0 = scale ? scale[lb] : 1.0;
-    const double t0 = block_sum_waves<NW>(s0 * f0, lds);
-    if (wave == 0) part[(i64)blockIdx.x * Bp + lb] = t0;
-    if (SPL == 2) {
-      const double f1 = scale ? scale[lb + 1] : 1.0;
-      const double t1 = block_sum_waves<NW>(s1 * f1, lds);
-      if (wave == 0) part[(i64)blockIdx.x * Bp + lb + 1] = t1;
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      const double f = scale ? scale[lb + q] : 1.0;
+      const double t = block_sum_waves<NW>(acc.v[q] * f, lds);
+      if (wave == 0) part[(i64)blockIdx.x * Bp + lb + q] = t;
     }
   }
 }
@@ -1618,7 +1662,7 @@ __global__ __launch_bounds__(64 * NW, SHARED ? 4 : 1) void fused_post_kernel(Lev
 template <typename VT, int ND, int RW, bool EDGE>
 __device__ __forceinline__ void cgstep2_body(const Level& L, VT beta, bool first, const float* __restrict__ z,
                                              const float* __restrict__ pin, float* __restrict__ pout, int Bp, unsigned lb,
-                                             int c0w, int r0, int r1, double& s0, double& s1) {
+                                             int c0w, int r0, int r1, Acc& acc) {
   constexpr int N = RW + 2;                  // window columns c0w - 1 + j
   const int W = L.W, nyp = L.ny + 1;
   const i64 n = L.n;
@@ -1634,8 +1678,8 @@ __device__ __forceinline__ void cgstep2_body(const Level& L, VT beta, bool first
     off[j] = 4u * ((unsigned)(c - (c0w - 1) + 1) * (unsigned)Bp + lb);      // base sits one column further left
   }
   const i64 tile0 = ((i64)(r0 - 1) * W + (c0w - 2)) * Bp;                  // element (r0 - 1, c0w - 2)
-  const rsrc_t rz = make_rsrc(z + tile0);
-  const rsrc_t rp = make_rsrc(first ? z + tile0 : pin + tile0);
+  const Src rz = make_src(z + tile0);
+  const Src rp = make_src(first ? z + tile0 : pin + tile0);
   const unsigned rowB = 4u * (unsigned)W * (unsigned)Bp;
   auto p_row = [&](int R, VT* dst) {
     if (EDGE && (R < 0 || R >= nyp)) {
@@ -1646,8 +1690,8 @@ __device__ __forceinline__ void cgstep2_body(const Level& L, VT beta, bool first
     const unsigned sx = (unsigned)(R - (r0 - 1)) * rowB;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      VT v = VLane<VT>::ld(rz, off[j], sx);
-      if (!first) v += beta * VLane<VT>::ld(rp, off[j], sx);
+      VT v = ldsrc<VT>(rz, off[j], sx);
+      if (!first) v += beta * ldsrc<VT>(rp, off[j], sx);
       dst[j] = ok[j] ? v : Z;
     }
   };
@@ -1660,7 +1704,7 @@ __device__ __forceinline__ void cgstep2_body(const Level& L, VT beta, bool first
     k1_row<VT, RW, ND, EDGE>(cf, n, W, row, c0w, a0, a1, a2, [&](int k, VT kx, float, float) {
       if (!EDGE || c0w + k < W) {
         __builtin_nontemporal_store(a1[k + 1], (VT*)(pp + (i64)k * Bp + lb));
-        VLane<VT>::dot(s0, s1, a1[k + 1], kx);
+        VLane<VT>::dot(acc, a1[k + 1], kx);
       }
     });
     pp += (i64)W * Bp;
@@ -1686,24 +1730,18 @@ __global__ __launch_bounds__(256, MW) void cgstep2_kernel(Level L, const double*
   const int c0w = (cb * 4 + wave) * RW;
   const int r0 = rc * TR;
   const int r1 = (r0 + TR < nyp) ? r0 + TR : nyp;
-  double s0 = 0.0, s1 = 0.0;
+  Acc acc;
   if (c0w < L.W && r0 < r1) {
-    VT bt = VLane<VT>::zero();
-    if (!first) {
-      if constexpr (SPL == 2) bt = VT{(float)beta[lb], (float)beta[lb + 1]};
-      else bt = (float)beta[lb];
-    }
+    const VT bt = first ? VLane<VT>::zero() : VLane<VT>::from_scale(beta, lb);
     const bool edge = c0w - 1 < 0 || c0w + RW > L.W - 1 || r0 - 1 < 0 || r1 > nyp - 1;
-    if (edge) cgstep2_body<VT, ND, RW, true>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, s0, s1);
-    else cgstep2_body<VT, ND, RW, false>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, s0, s1);
+    if (edge) cgstep2_body<VT, ND, RW, true>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, acc);
+    else cgstep2_body<VT, ND, RW, false>(L, bt, first != 0, z, pin, pout, Bp, lb, c0w, r0, r1, acc);
   }
-  const double f0 = scale ? scale[lb] : 1.0;
-  const double t0 = block_sum_per_sample(s0 * f0, Bp, lds);
-  if (wave == 0) part[(i64)blockIdx.x * Bp + lb] = t0;
-  if (SPL == 2) {
-    const double f1 = scale ? scale[lb + 1] : 1.0;
-    const double t1 = block_sum_per_sample(s1 * f1, Bp, lds);
-    if (wave == 0) part[(i64)blockIdx.x * Bp + lb + 1] = t1;
+#pragma unroll
+  for (int q = 0; q < SPL; ++q) {
+    const double f = scale ? scale[lb + q] : 1.0;
+    const double t = block_sum_per_sample(acc.v[q] * f, Bp, lds);
+    if (wave == 0) part[(i64)blockIdx.x * Bp + lb + q] = t;
   }
 }
 
@@ -1831,7 +1869,7 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
 inline int fused_mode() {
   static const int on = getenv("DIFFHE_FUSED") ? atoi(getenv("DIFFHE_FUSED")) : 1;
   static const int spl = getenv("DIFFHE_FUSED_SPL") ? atoi(getenv("DIFFHE_FUSED_SPL")) : 2;
-  return on ? (spl == 1 ? 1 : 2) : 0;
+  return on ? (spl == 1 ? 1 : (spl == 4 ? 4 : 2)) : 0;
 }
 inline unsigned fused_lds() {
   // dynamic LDS per block = a cap on the blocks resident per CU; the fused passes (118-125 VGPRs: 4 waves per SIMD
@@ -1875,29 +1913,27 @@ inline int fused_ok(const Level& L, int Bv, int Bp, const double* scale) {
   return (Bv == Bp && Bp % (2 * kWave) == 0 && L.v32 && L.o16 && L.mk32 && !L.shift && !scale) ? per_sample : 0;
 }
 
-// waves per block of the fused passes of a batch-shared matrix (4, 8 or 16; per-sample matrices keep 4)
-inline int fused_nw() {
-  static const int v = getenv("DIFFHE_FUSED_NW") ? atoi(getenv("DIFFHE_FUSED_NW")) : 4;
-  return (v == 8 || v == 16) ? v : 4;
-}
-
 void launch_fused_pre(const Level& L, const Level& C, int Bv, const double* scale, const float* rhs, float* x2, float* crhs,
                       double w0, double w1, int Bp, const StripGeom& g, int spl, hipStream_t st, int nw = 4) {
   constexpr int CW = kRestrictCols;
   // r read, x2 and the coarse rhs written; per-sample matrices: + the compact coefficients (read by both stages)
   diffhe::account((9.0 + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPREN(VT_, ND_, SH_, NW_)                                                                                         \
-  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW, SH_, NW_>), grid, dim3(64 * NW_), fused_lds(), st, L, scale, rhs, x2, \
-                     crhs, (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
-#define FPRE(VT_, ND_, SH_) FPREN(VT_, ND_, SH_, 4)
-  if (Bv != 1) { if (L.nd == 3) FPRE(v2f, 3, false); else FPRE(v2f, 4, false); }
-  else if (spl == 2 && nw == 8 && L.nd == 3) FPREN(v2f, 3, true, 8);
-  else if (spl == 2 && nw == 16 && L.nd == 3) FPREN(v2f, 3, true, 16);
-  else if (spl == 2) { if (L.nd == 3) FPRE(v2f, 3, true); else FPRE(v2f, 4, true); }
+#define FPRE(VT_, ND_, SH_)                                                                                               \
+  hipLaunchKernelGGL((fused_pre_kernel<VT_, ND_, CW, SH_>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,     \
+                     (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR)
+  // per-sample coefficients: 206 VGPRs = 2 waves per SIMD; capped at 168 (3 waves) it spills and loses (launch_fused_post)
+  static const int ps_mw = getenv("DIFFHE_FUSED_PS_MW") ? atoi(getenv("DIFFHE_FUSED_PS_MW")) : 2;
+  if (Bv != 1 && L.nd == 3 && (ps_mw & 1))
+    hipLaunchKernelGGL((fused_pre_kernel<v2f, 3, CW, false, 4, 3>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,
+                       (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR);
+  else if (Bv != 1) { if (L.nd == 3) FPRE(v2f, 3, false); else FPRE(v2f, 4, false); }
+  else if (spl == 4 && L.nd == 3)
+    hipLaunchKernelGGL((fused_pre_kernel<v4f, 3, CW, true, 4, 2>), grid, dim3(256), fused_lds(), st, L, scale, rhs, x2, crhs,
+                       (float)w0, (float)w1, C.W, C.bc, Bp, g.ncb, g.TR);
+  else if (spl >= 2) { if (L.nd == 3) FPRE(v2f, 3, true); else FPRE(v2f, 4, true); }
   else { if (L.nd == 3) FPRE(float, 3, true); else FPRE(float, 4, true); }
 #undef FPRE
-#undef FPREN
 }
 
 void launch_fused_post(const Level& L, const Level& C, int Bv, const double* scale, const float* xin, const float* rhs,
@@ -1906,32 +1942,38 @@ void launch_fused_post(const Level& L, const Level& C, int Bv, const double* sca
   // x2, r, a quarter of e read; z written (+ compact coefficients of a per-sample matrix); xin == NULL: x2 = 0, not read
   diffhe::account(((xin ? 13.0 : 9.0) + (Bv == 1 ? 0.0 : 4.0 + 2.0 * (L.nd - 1))) * (double)L.n * Bp);
   const dim3 grid(g.ncb * g.nrc, Bp / (spl * kWave));
-#define FPOSTN(VT_, ND_, DOT_, SH_, XZ_, NW_)                                                                                \
-  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_, XZ_, NW_>), grid, dim3(64 * NW_), fused_lds(), st, L, scale, xin, \
-                     rhs, ec, z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
-#define FPOST(VT_, ND_, DOT_, SH_, XZ_) FPOSTN(VT_, ND_, DOT_, SH_, XZ_, 4)
+#define FPOST(VT_, ND_, DOT_, SH_, XZ_)                                                                                      \
+  hipLaunchKernelGGL((fused_post_kernel<VT_, ND_, 4, DOT_, SH_, XZ_>), grid, dim3(256), fused_lds(), st, L, scale, xin, rhs, ec, \
+                     z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
 #define FPOSTD(VT_, ND_, SH_)                                                                                              \
   do {                                                                                                                     \
     if (!xin) FPOST(VT_, ND_, false, SH_, true);                                                                          \
     else if (part) FPOST(VT_, ND_, true, SH_, false);                                                                     \
     else FPOST(VT_, ND_, false, SH_, false);                                                                              \
   } while (0)
-  if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
-  else if (spl == 2 && (nw == 8 || nw == 16) && L.nd == 3) {
-#define FPOSTDN(NW_)                                                                                                       \
-  do {                                                                                                                     \
-    if (!xin) FPOSTN(v2f, 3, false, true, true, NW_);                                                                      \
-    else if (part) FPOSTN(v2f, 3, true, true, false, NW_);                                                                 \
-    else FPOSTN(v2f, 3, false, true, false, NW_);                                                                          \
-  } while (0)
-    if (nw == 8) FPOSTDN(8); else FPOSTDN(16);
-#undef FPOSTDN
+  // per-sample coefficients: the POST pass needs 173 VGPRs uncapped (176 allocated: 2 waves per SIMD); capped at 168 it runs
+  // 3 waves per SIMD without spills: 218.1 -> 213.5 ms per 1024^2 x 256 step of the per-element-field workload; the PRE pass
+  // (206 VGPRs) spills under the same cap: 248.9 ms (gpurun_out/r4e).  DIFFHE_FUSED_PS_MW: bit 0 = PRE, bit 1 = POST capped
+  static const int ps_mw = getenv("DIFFHE_FUSED_PS_MW") ? atoi(getenv("DIFFHE_FUSED_PS_MW")) : 2;
+  if (Bv != 1 && L.nd == 3 && (ps_mw & 2)) {
+#define FPOSTM(DOT_, XZ_)                                                                                                  \
+  hipLaunchKernelGGL((fused_post_kernel<v2f, 3, 4, DOT_, false, XZ_, 4, 3>), grid, dim3(256), fused_lds(), st, L, scale, xin, \
+                     rhs, ec, z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+    if (!xin) FPOSTM(false, true); else if (part) FPOSTM(true, false); else FPOSTM(false, false);
+#undef FPOSTM
   }
-  else if (spl == 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
+  else if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
+  else if (spl == 4 && L.nd == 3) {
+#define FPOST4(DOT_, XZ_)                                                                                                  \
+  hipLaunchKernelGGL((fused_post_kernel<v4f, 3, 4, DOT_, true, XZ_, 4, 2>), grid, dim3(256), fused_lds(), st, L, scale, xin, \
+                     rhs, ec, z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
+    if (!xin) FPOST4(false, true); else if (part) FPOST4(true, false); else FPOST4(false, false);
+#undef FPOST4
+  }
+  else if (spl >= 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
   else { if (L.nd == 3) FPOSTD(float, 3, true); else FPOSTD(float, 4, true); }
 #undef FPOSTD
 #undef FPOST
-#undef FPOSTN
 }
 
 // One step of the Chebyshev semi-iteration (three-term form) on the coarsest level:
@@ -2270,6 +2312,10 @@ __global__ __launch_bounds__(256) void pcg_axpy_kernel(const double* __restrict_
   }
 }
 
+// Directions kept before the iterate is touched: 10 fp32 slots (5 fp64) -- solves of up to 10 iterations (the 9 + 9 of a
+// per-element field per sample) form x ONCE, in pcg_finish_kernel; round 3's 6 slots flushed such a solve twice
+constexpr int kRingSlots = 10;
+
 // End of the solve: x += alpha p (the pending iterate update of the fused loop; p == NULL: none) + z / rs, where
 // z = V(r) is the preconditioned residual of the FINAL iterate -- every iteration ends with that V-cycle (its r.z is
 // the error estimate the stop is decided on), and samples that stopped earlier kept r, hence z, unchanged since.
@@ -2284,15 +2330,15 @@ __global__ __launch_bounds__(256) void pcg_finish_kernel(const double* __restric
   // step lengths in row j % n_slots of `alpha` (0 for samples that had stopped)
   const NodeMap nm = node_map(Bp);
   const double zi = z ? (rs ? 1.0 / rs[nm.b] : 1.0) : 0.0;   // rs is a power of two: exact
-  double a[8];
+  double a[kRingSlots];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = k < count ? alpha[(long long)((j0 + k) % n_slots) * Bp + nm.b] : 0.0;
+  for (int k = 0; k < kRingSlots; ++k) a[k] = k < count ? alpha[(long long)((j0 + k) % n_slots) * Bp + nm.b] : 0.0;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     double v = x[o];
     if (z) v += zi * (double)z[o];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < kRingSlots; ++k)
       if (k < count) v += a[k] * (double)p[(long long)((j0 + k) % n_slots) * slot_stride + o];
     x[o] = v;
   }
@@ -2332,6 +2378,32 @@ struct PcgScalars {
 };
 enum { S_INIT = 0, S_RZ0 = 1, S_ALPHA = 2, S_CONV = 3, S_BETA = 4, S_RELRES = 5, S_SUM = 6, S_FLOOR = 7, S_ENERGY = 8,
        S_ENERGY2 = 9 };
+
+// First stage of a long partial list: block (x, y) sums the rows k = y, y + S, y + 2 S, ... of `part` for the samples of
+// chunk x into row y of `slice` (S = gridDim.y rows).  One block of pcg_scalar_kernel summing 1500-2000 rows reads ~1 MB
+// through ONE CU (23 us per phase at 1024^2 x 256, 43 phases per step); 16 blocks + the final phase over 16 rows take ~8.
+// Fixed assignment and fixed order of additions: bitwise reproducible.
+constexpr int kScalarSlices = 16;
+__global__ __launch_bounds__(256) void pcg_slice_kernel(const double* __restrict__ part, int nblk, int Bp,
+                                                         double* __restrict__ slice) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWave + lane;
+  const int S = gridDim.y, y = blockIdx.y;
+  double s0 = 0.0, s1 = 0.0;
+  if (b < Bp) {
+    int k = y + S * wave;
+    for (; k + 4 * S < nblk; k += 8 * S) {     // two independent chains per wave, four waves: eight loads in flight
+      s0 += part[(i64)k * Bp + b];
+      s1 += part[(i64)(k + 4 * S) * Bp + b];
+    }
+    if (k < nblk) s0 += part[(i64)k * Bp + b];
+  }
+  lds[wave * kWave + lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && b < Bp)
+    slice[(i64)y * Bp + b] = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
+}
 
 // 1024 threads: lanes over samples, 16 waves over slices of the partial list (fixed order)
 __global__ __launch_bounds__(1024) void pcg_scalar_kernel(int phase, const double* __restrict__ part, int nblk, int Bp,
@@ -2845,11 +2917,11 @@ void resid_restrict(const Hier& H, int l, const TV* x, const TV* rhs_l, hipStrea
   if (l == 0) kp_end(KP_RESTRICT, st);
 }
 
-// waves per block of the fused passes on level L: the wide blocks for the two-samples-per-lane kernels of a batch-shared
-// 3-diagonal matrix on levels wide enough to fill them
-inline int fused_nw_for(const Hier& H, const Level& L) {
-  const int nw = fused_nw();
-  return (H.Bv == 1 && H.fuse == 2 && L.nd == 3 && L.W > 300) ? nw : 4;
+// samples per lane of the fused passes on level L: per-sample matrices always two; a batch-shared matrix what the batch
+// allows (H.fuse), the four-sample form for 3-diagonal levels only
+inline int fused_spl(const Hier& H, const Level& L) {
+  const int spl = H.Bv == 1 ? H.fuse : 2;
+  return (spl == 4 && L.nd != 3) ? 2 : spl;
 }
 
 // Can level l of the fp32 cycle run the fused POST pass (and with it the initial-guess form of the cycle)?  Fills the
@@ -2861,8 +2933,8 @@ int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
   const Level& C = H.lev[l + 1];
   const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
   if (!fmask || !(L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use)) return 0;
-  const int spl = H.Bv == 1 ? H.fuse : 2;   // per-sample matrices: always two samples per lane
-  const int nw = fused_nw_for(H, L);
+  const int spl = fused_spl(H, L);
+  const int nw = 4;   // waves per block (fused_pre_kernel: wider blocks measured slower)
   constexpr int CW = kRestrictCols;
   StripGeom g{true, 0, 0, 0};
   g.ncb = (C.W + nw * CW - 1) / (nw * CW);
@@ -2927,12 +2999,12 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     const int fmask = fused_level<TV>(H, l, &gpre, &gpost[l]);
     if (fmask) {
       const Level& C = H.lev[l + 1];
-      const int spl = H.Bv == 1 ? H.fuse : 2;
+      const int spl = fused_spl(H, L);
       fused[l] = (fmask & 2) != 0;             // the way up: fused POST pass
       if (l == l0 && guess && fused[l]) {
         // two sweeps from the prolonged guess (the POST kernel with x = 0), then residual + restriction
         launch_fused_post(L, C, H.Bv, H.scale, (const float*)nullptr, (const float*)rhs[l], (const float*)guess, (float*)a,
-                          H.omega[0], H.omega[1], nullptr, H.Bp, gpost[l], spl, st, fused_nw_for(H, L));
+                          H.omega[0], H.omega[1], nullptr, H.Bp, gpost[l], spl, st);
         resid_restrict<TV>(H, l, a, rhs[l], st);
         cur[l] = a;
         rhs[l + 1] = (const TV*)H.rhs[l + 1];
@@ -2942,7 +3014,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         // both sweeps + residual + restriction in ONE pass (fused_pre_kernel)
         if (l == 0) kp_begin(KP_FIRST2, st);
         launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
-                         H.omega[1], H.Bp, gpre, spl, st, fused_nw_for(H, L));
+                         H.omega[1], H.Bp, gpre, spl, st);
         if (l == 0) kp_end(KP_FIRST2, st);
         cur[l] = a;
         rhs[l + 1] = (const TV*)H.rhs[l + 1];
@@ -2989,8 +3061,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       const bool dot = (l == l0) && rz_part;
       if (l == 0) kp_begin(KP_PROLONG, st);
       launch_fused_post(L, C, H.Bv, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
-                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], H.Bv == 1 ? H.fuse : 2, st,
-                        fused_nw_for(H, L));
+                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], fused_spl(H, L), st);
       if (l == 0) kp_end(KP_PROLONG, st);
       if (dot && rz_blocks) *rz_blocks = gpost[l].ncb * gpost[l].nrc;
       cur[l] = b2;
@@ -3141,7 +3212,8 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
   H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
   H.fuse = fused_mode();
-  if (H.fuse == 2 && Bp % (2 * kWave) != 0) H.fuse = 1;   // one sample per lane where the batch is no multiple of 128
+  if (H.fuse == 4 && Bp % (4 * kWave) != 0) H.fuse = 2;   // samples per lane: as many as the batch has whole waves of
+  if (H.fuse == 2 && Bp % (2 * kWave) != 0) H.fuse = 1;
   H.dense_mfma = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
@@ -3176,7 +3248,8 @@ extern "C" long long diffhe_lattice_pcg_workspace_doubles(const diffhe_mg_level*
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = lgrid(H.lev[0].n, Bp).x;
   (void)nblk;
-  return carve(H, nullptr, false) + 5 * nb + 2LL * kPartBlocks * Bp + 32LL * Bp + 64;  // fp64 layout is the larger
+  // r, the direction ring (kRingSlots fp32 = kRingSlots / 2 fp64 vectors), A p; the fp64 layout of the cycle is the larger
+  return carve(H, nullptr, false) + (2 + kRingSlots / 2) * nb + 2LL * kPartBlocks * Bp + (32LL + kScalarSlices) * Bp + 64;
 }
 
 extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_levels, int Bv, const double* scale,
@@ -3203,13 +3276,13 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;
   // Search directions.  Fused loop: the iterate is NOT touched inside the loop (that cost 16 of the fused step's 36
-  // bytes per node); the directions p_j stay in a ring of slots (6 fp32 / 3 fp64 vectors in these 3 nb doubles) with
+  // bytes per node); the directions p_j stay in a ring of slots (10 fp32 / 5 fp64 vectors in these 5 nb doubles) with
   // their step lengths alpha_j, and x += sum_j alpha_j p_j is formed when the ring is full or the solve ends.
   // Unfused loop (small meshes / batches): one fp64 p in the same region, x updated every iteration.
   double* p = r + nb;
-  const int n_slots = f32 ? 6 : 3;
+  const int n_slots = f32 ? kRingSlots : kRingSlots / 2;
   const long long slot_stride = nb;              // in elements of the stored type: fp32 slots are nb floats apart
-  double* Ap = p + 3 * nb;
+  double* Ap = p + (kRingSlots / 2) * nb;
   double* partA = Ap + nb;
   double* partB = partA + (long long)kPartBlocks * Bp;
   double* sc = partB + (long long)kPartBlocks * Bp;
@@ -3227,7 +3300,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   S.est = err_est ? err_est : sc + 13 * Bp;
   S.rr = sc + 14 * Bp;
   S.rule = stop_rule ? stop_rule : (int*)(sc + 7 * Bp);
-  double* alpha_ring = sc + 16 * Bp;              // n_slots (<= 6) rows of Bp step lengths
+  double* alpha_ring = sc + 16 * Bp;              // n_slots (<= 10) rows of Bp step lengths (the scalar block has 32 rows)
   double* const alpha_single = S.alpha;
   // tol_energy is asked of the FINAL iterate, which receives one more multigrid correction after the decision
   // (pcg_finish_kernel): the CG iterate's own estimate may be 1 / 0.3 of it (0.3: a cautious bound of the V(2,2)
@@ -3256,8 +3329,20 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     }
   }
   const dim3 sgrid((Bp + 63) / 64);
-#define SCALAR(phase, part, nb_) \
-  hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp, tol, S, relres)
+  double* const slices = sc + 32LL * Bp;          // kScalarSlices rows: first stage of long partial lists
+  static const int two_stage = getenv("DIFFHE_SCALAR2") ? atoi(getenv("DIFFHE_SCALAR2")) : 1;
+#define SCALAR(phase, part, nb_)                                                                                           \
+  do {                                                                                                                     \
+    if (two_stage && (int)(nb_) >= 256) {                                                                                  \
+      hipLaunchKernelGGL(pcg_slice_kernel, dim3(sgrid.x, kScalarSlices), dim3(256), 0, st, (const double*)(part), (int)(nb_), \
+                         Bp, slices);                                                                                      \
+      hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)slices, kScalarSlices, Bp, \
+                         tol, S, relres);                                                                                  \
+    } else {                                                                                                               \
+      hipLaunchKernelGGL(pcg_scalar_kernel, sgrid, dim3(1024), 0, st, (int)(phase), (const double*)(part), (int)(nb_), Bp,   \
+                         tol, S, relres);                                                                                  \
+    }                                                                                                                      \
+  } while (0)
 
   for (int l = 0; l < H.nl; ++l)
     if (H.lev[l].shift && (H.lev[l].inv || Bv != 1)) return DIFFHE_E_BADARG;  // a shift belongs to a factored operator

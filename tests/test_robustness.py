@@ -649,8 +649,10 @@ def test_per_sample_fields_of_very_different_magnitudes_share_a_batch():
     """kappa_b(x) = c_b exp(0.3 randn) with c_b spread over 1e-6 .. 1e6 across the batch.  The fp16 couplings of the
     V-cycle are stored relative to a PER-SAMPLE power of two (the sample's largest free-row diagonal; the identity rows
     of Dirichlet nodes, 1.0 whatever kappa is, do not count), so every sample keeps 11 bits: compact coefficients stay in
-    use, iteration counts are those of an all-O(1) batch, and the answers meet the oracle."""
-    mesh = FEMesh.rectangle(256, 240, bc_value=0.25)
+    use and the iteration counts are those of an all-O(1) batch.  With homogeneous Dirichlet data u scales by 1 / c_b,
+    dL/df by 1 / c_b^2 and dL/dkappa_e by 1 / c_b^3 EXACTLY (L = sum u^2), so every sample is checked against the c = 1
+    run; three samples against the oracle as well."""
+    mesh = FEMesh.rectangle(256, 240)
     B, n, m = 128, mesh.n_nodes, mesh.n_elements
     gen = torch.Generator().manual_seed(21)
     base = torch.exp(0.3 * torch.randn(B, m, generator=gen, dtype=T64))
@@ -662,6 +664,10 @@ def test_per_sample_fields_of_very_different_magnitudes_share_a_batch():
     assert new[3].coeff_storage == "fp16-rowsum" and ref[3].coeff_storage == "fp16-rowsum"
     assert new[3].not_converged == 0 and bool(torch.isfinite(new[0]).all()) and bool(torch.isfinite(new[1]).all())
     assert new[3].iterations <= ref[3].iterations + 1 and new[3].adj_iterations <= ref[3].adj_iterations + 1
+    mg_ = mag.to(DEV)[:, None]
+    for a_, b_, p_ in ((new[0], ref[0], 1), (new[1], ref[1], 3), (new[2], ref[2], 2)):
+        worst = float(((a_ * mg_ ** p_ - b_).abs().amax(dim=1) / b_.abs().amax(dim=1)).max())
+        assert worst < RTOL_U, (p_, worst)
     bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
     for b in (0, B // 2, B - 1):
         uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, (base[b] * mag[b]).numpy(),
@@ -739,3 +745,34 @@ def test_no_kernel_reads_in_front_of_the_coefficient_arrays(B):
                                     rdiag32=[behind_nan(r) for r in rd32])
         assert plain[2] == 0 and moved[2] == 0 and bool(torch.isfinite(moved[0]).all())
         assert torch.equal(plain[0], moved[0]) and plain[1] == moved[1]
+
+
+# ---- batches that are no multiple of 128: the fused passes with ONE sample per lane (BASELINE config 5: 64 per GPU) -----
+@pytest.mark.parametrize("B", [64, 192])
+@pytest.mark.parametrize("name,mesh_fn", [("uniform 256^2", lambda: FEMesh.rectangle(256, 256)),
+                                          ("odd sizes, non-zero Dirichlet data", lambda: FEMesh.rectangle(333, 207, bc_value=0.7)),
+                                          ("skewed lattice (4 diagonals)", lambda: _skewed(272, 232))])
+def test_batches_of_64_and_192_take_the_fused_kernels_with_one_sample_per_lane(name, mesh_fn, B):
+    """B = 64 (config 5's per-GPU shard) and 192 are whole waves but no multiple of 128: the V-cycle of a batch-shared matrix
+    runs the same fused two-stage passes and the fp32 CG step with one sample per lane (round 3 sent them to the four
+    single-stage fp64-in-register passes).  Same preconditioner up to fp32 rounding: iteration counts as with the old
+    kernels (mg strip2 = 0), answers equal far inside the tolerance, and equal to the oracle."""
+    mesh = mesh_fn()
+    n = mesh.n_nodes
+    gen = torch.Generator().manual_seed(78)
+    kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    new = _run(mesh, kappa, f)
+    old = _run(mesh, kappa, f, mg=dict(strip2=0))
+    assert new[3].path == "lattice-mgpcg" and new[3].not_converged == 0 and old[3].not_converged == 0
+    assert new[3].coeff_storage == "shared-fp32" and "one sample per lane" in new[3].precision
+    assert abs(new[3].iterations - old[3].iterations) <= 1 and abs(new[3].adj_iterations - old[3].adj_iterations) <= 1
+    for a, b in zip(new[:3], old[:3]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-11, name
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B - 1):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, float(kappa[b]), f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=1)
+        assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U, name
+        assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD, name
+        assert abs(float(new[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum()), name
