@@ -806,7 +806,7 @@ KERNEL_NAME_RUPD = "residual update with A p recomputed from the stored p: r -= 
 KERNEL_SYMBOL_RUPD = "dia_strip_kernel<double, float, double, 0, 5, 3, true, false, 4, 5>"
 
 
-KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(2), 3, 2, true, 4, 4>",
+KERNEL_SYMBOLS_FUSED = [KERNEL_SYMBOLS_FP32[0], "pcg_update_kernel", "fused_pre_kernel<float __vector(4), 3, 2, true, 4, 2>",
                         KERNEL_SYMBOLS_FP32[3], "fused_post_kernel<float __vector(2), 3, 4, true, true, false, 4, 4>",
                         KERNEL_SYMBOLS_FP32[5]]
 

@@ -1395,6 +1395,12 @@ __global__ __launch_bounds__(64 * NW, MW) void fused_pre_kernel(Level L, const d
 
 // ---- POST: prolongation + correction + both post-smoothing sweeps (+ the partials of rhs . z) ------------------------
 // The wave owns the RW columns c0w .. c0w + RW - 1 (c0w a multiple of RW, even); rows r0 .. r1 - 1.
+// Round 4 built and measured a variant in which the 4 waves of a block EXCHANGE their halo columns through LDS instead of
+// each loading (and prolongating) them again: 12 instead of 23 vector-memory loads per wave and fine row, x' and r / s_b
+// written to a two-slot exchange area, ONE workgroup barrier per row.  Correct (28 GPU tests, same iteration counts) and
+// TWICE as slow: 0.999 -> 2.035 ms per fine-level launch at 1024^2 x 256 (gpurun_out/r4o).  The barrier puts the block's
+// waves in lockstep, and these passes live on their waves being at DIFFERENT points of the row loop (one wave's loads in
+// flight under another's arithmetic); any block-cooperative staging of rows pays the same price.  Removed.
 template <typename VT, int ND, int RW, bool EDGE, bool DOT, bool SHARED, bool XZ>
 __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const float* __restrict__ xin,
                                                 const float* __restrict__ rhs, const float* __restrict__ ec,
@@ -1869,7 +1875,7 @@ void launch_strip2(const Level& L, const double* scale, const float* xin, const 
 inline int fused_mode() {
   static const int on = getenv("DIFFHE_FUSED") ? atoi(getenv("DIFFHE_FUSED")) : 1;
   static const int spl = getenv("DIFFHE_FUSED_SPL") ? atoi(getenv("DIFFHE_FUSED_SPL")) : 2;
-  return on ? (spl == 1 ? 1 : (spl == 4 ? 4 : 2)) : 0;
+  return on ? (spl == 1 ? 1 : 2) : 0;
 }
 inline unsigned fused_lds() {
   // dynamic LDS per block = a cap on the blocks resident per CU; the fused passes (118-125 VGPRs: 4 waves per SIMD
@@ -1963,13 +1969,6 @@ void launch_fused_post(const Level& L, const Level& C, int Bv, const double* sca
 #undef FPOSTM
   }
   else if (Bv != 1) { if (L.nd == 3) FPOSTD(v2f, 3, false); else FPOSTD(v2f, 4, false); }
-  else if (spl == 4 && L.nd == 3) {
-#define FPOST4(DOT_, XZ_)                                                                                                  \
-  hipLaunchKernelGGL((fused_post_kernel<v4f, 3, 4, DOT_, true, XZ_, 4, 2>), grid, dim3(256), fused_lds(), st, L, scale, xin, \
-                     rhs, ec, z, (float)wA, (float)wB, C.W, part, Bp, g.ncb, g.TR)
-    if (!xin) FPOST4(false, true); else if (part) FPOST4(true, false); else FPOST4(false, false);
-#undef FPOST4
-  }
   else if (spl >= 2) { if (L.nd == 3) FPOSTD(v2f, 3, true); else FPOSTD(v2f, 4, true); }
   else { if (L.nd == 3) FPOSTD(float, 3, true); else FPOSTD(float, 4, true); }
 #undef FPOSTD
@@ -2559,6 +2558,7 @@ struct Hier {
   double omega[8];  // per-sweep damping (Chebyshev-weighted Jacobi); post-smoothing runs them in reverse
   int nu, n_coarse, fmg_coarse_cycles;
   int fuse;  // 0: four single-stage strip passes per level; 1 / 2: fused two-stage passes, samples per lane
+  int pre4;  // the fused PRE pass may take four samples per lane (fused_spl)
   int dense_mfma;  // coarsest-level dense solve of an fp32 cycle on the matrix cores (0: scalar-load kernel)
   double coarse_lmax;  // upper bound of the spectrum of D^-1 A on the coarsest level (2 for an M-matrix)
   // per-level work vectors
@@ -2919,9 +2919,15 @@ void resid_restrict(const Hier& H, int l, const TV* x, const TV* rhs_l, hipStrea
 
 // samples per lane of the fused passes on level L: per-sample matrices always two; a batch-shared matrix what the batch
 // allows (H.fuse), the four-sample form for 3-diagonal levels only
-inline int fused_spl(const Hier& H, const Level& L) {
+// The PRE pass of a 3-diagonal batch-shared level takes FOUR samples per lane where the batch has whole waves of 256:
+// half the vector-memory instructions per byte at half the waves (219 VGPRs, 2 waves per SIMD).  Measured on the
+// 1024^2 x 256 bench, same box (gpurun_out/r4k): PRE 0.707 -> 0.659 ms; the POST pass (240 VGPRs) 0.998 -> 1.042 ms:
+// it keeps two.  DIFFHE_FUSED_PRE4=0 switches the four-sample form off.
+inline int fused_spl(const Hier& H, const Level& L, bool pre) {
   const int spl = H.Bv == 1 ? H.fuse : 2;
-  return (spl == 4 && L.nd != 3) ? 2 : spl;
+  static const int pre4 = getenv("DIFFHE_FUSED_PRE4") ? atoi(getenv("DIFFHE_FUSED_PRE4")) : 1;
+  if (pre && pre4 && H.pre4 && H.Bv == 1 && spl == 2 && H.Bp % (4 * kWave) == 0 && L.nd == 3) return 4;
+  return spl;
 }
 
 // Can level l of the fp32 cycle run the fused POST pass (and with it the initial-guess form of the cycle)?  Fills the
@@ -2933,12 +2939,15 @@ int fused_level(const Hier& H, int l, StripGeom* gpre, StripGeom* gpost) {
   const Level& C = H.lev[l + 1];
   const int fmask = (sizeof(TV) == 4 && H.fuse && H.nu == 2) ? fused_ok(L, H.Bv, H.Bp, H.scale) : 0;
   if (!fmask || !(L.nx == 2 * C.nx && L.ny == 2 * C.ny && strip_geom(L, H.Bp).use)) return 0;
-  const int spl = fused_spl(H, L);
+  const int spl = fused_spl(H, L, false), spl_pre = fused_spl(H, L, true);
   const int nw = 4;   // waves per block (fused_pre_kernel: wider blocks measured slower)
   constexpr int CW = kRestrictCols;
   StripGeom g{true, 0, 0, 0};
   g.ncb = (C.W + nw * CW - 1) / (nw * CW);
-  const int gy = H.Bp / (spl * kWave);
+  const int gy = H.Bp / (spl_pre * kWave);
+  // ~6144 blocks whatever the samples per lane: the four-sample form gets tiles of half the height (6 instead of 11 coarse
+  // rows at 1024^2 x 256).  Measured (gpurun_out/r4l, same box): 6 rows 0.660 ms, 11 rows 0.681, 16 rows 0.778 -- the
+  // number of independent marches matters more than the halo rows
   int nrc = (6144 * 4 / nw + g.ncb * gy - 1) / (g.ncb * gy);
   // Levels of <= 300 columns cannot fill the GPU with 4-coarse-row tiles: shorter tiles (2 coarse rows going down, ~5 fine
   // rows going up) double the independent marches; -1.4 ms per 1024^2 step, neutral on the 513^2 level (gpurun_out/r5j, r5k)
@@ -2999,7 +3008,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
     const int fmask = fused_level<TV>(H, l, &gpre, &gpost[l]);
     if (fmask) {
       const Level& C = H.lev[l + 1];
-      const int spl = fused_spl(H, L);
+      const int spl = fused_spl(H, L, false);
       fused[l] = (fmask & 2) != 0;             // the way up: fused POST pass
       if (l == l0 && guess && fused[l]) {
         // two sweeps from the prolonged guess (the POST kernel with x = 0), then residual + restriction
@@ -3014,7 +3023,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
         // both sweeps + residual + restriction in ONE pass (fused_pre_kernel)
         if (l == 0) kp_begin(KP_FIRST2, st);
         launch_fused_pre(L, C, H.Bv, H.scale, (const float*)rhs[l], (float*)a, (float*)H.rhs[l + 1], H.omega[0],
-                         H.omega[1], H.Bp, gpre, spl, st);
+                         H.omega[1], H.Bp, gpre, fused_spl(H, L, true), st);
         if (l == 0) kp_end(KP_FIRST2, st);
         cur[l] = a;
         rhs[l + 1] = (const TV*)H.rhs[l + 1];
@@ -3061,7 +3070,7 @@ TV* vcycle(const Hier& H, const TV* rhs0, double* rz_part, int* rz_blocks, hipSt
       const bool dot = (l == l0) && rz_part;
       if (l == 0) kp_begin(KP_PROLONG, st);
       launch_fused_post(L, C, H.Bv, H.scale, (const float*)a, (const float*)rhs[l], (const float*)cur[l + 1], (float*)b2,
-                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], fused_spl(H, L), st);
+                        H.omega[1], H.omega[0], dot ? rz_part : nullptr, H.Bp, gpost[l], fused_spl(H, L, false), st);
       if (l == 0) kp_end(KP_PROLONG, st);
       if (dot && rz_blocks) *rz_blocks = gpost[l].ncb * gpost[l].nrc;
       cur[l] = b2;
@@ -3212,8 +3221,8 @@ static int fill_hier(Hier& H, const diffhe_mg_level* levels, int n_levels, int B
   H.coarse_lmax = 2.0;
   H.fmg_coarse_cycles = 1;
   H.fuse = fused_mode();
-  if (H.fuse == 4 && Bp % (4 * kWave) != 0) H.fuse = 2;   // samples per lane: as many as the batch has whole waves of
-  if (H.fuse == 2 && Bp % (2 * kWave) != 0) H.fuse = 1;
+  H.pre4 = 1;
+  if (H.fuse == 2 && Bp % (2 * kWave) != 0) H.fuse = 1;   // one sample per lane where the batch is no multiple of 128
   H.dense_mfma = 1;
   for (int k = 0; k < 8; ++k) H.omega[k] = omegas[k < nu ? k : nu - 1];
   return DIFFHE_OK;
@@ -3272,6 +3281,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   H.fmg_coarse_cycles = 1 + ((precond_fp32 >> 2) & 3);
   if (precond_fp32 & 64) H.fuse = 0;             // bit 6: keep the four single-stage passes (A/B runs, tests)
   if (precond_fp32 & 128) H.dense_mfma = 0;      // bit 7: scalar-load dense coarse solve
+  if (precond_fp32 & 512) H.pre4 = 0;            // bit 9: fused PRE pass with two samples per lane as well (A/B runs, tests)
   double* w = work + carve(H, work, f32);
   float* r32 = f32 ? (float*)H.rhs[0] : nullptr;
   double* r = w;
@@ -3391,6 +3401,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const bool rupd = fused && f32 && Bv == 1 && rupd_mode != 0;
   const StripGeom g8 = strip_geom(L0, Bp, 8);
   // cgstep2_kernel: two samples per lane for batches that are multiples of 128, else one
+  // (four samples per lane -- what pays in the fused PRE pass -- measured here too: 0.699 -> 0.711 ms at 4 waves per SIMD
+  // instead of 8, gpurun_out/r4n; not kept)
   const int cspl = (Bp % (2 * kWave) == 0) ? 2 : 1;
   const StripGeom g2 = (Bp % kWave == 0) ? strip_geom(L0, Bp, 4, cspl) : StripGeom{false, 0, 0, 0};
   const void* z = nullptr;

@@ -393,6 +393,7 @@ class _Engine:
         flags = (int(mg.get("fp32", 0)) | (int(mg.get("fmg", 0)) << 1) | ((int(mg.get("fmg_cycles", 1)) - 1) << 2)
                  | ((0 if int(mg.get("floor", 1)) else 1) << 4) | (32 if warm else 0)
                  | (0 if int(mg.get("fused", 1)) else 64) | (0 if int(mg.get("dense_mfma", 1)) else 128)
+                 | (0 if int(mg.get("pre4", 1)) else 512)
                  | (256 if (p.closed_boundary and p.regular_cells and p.dense_level() is not None
                             and int(mg.get("cg_fp32_steplength", 1))) else 0))
         self.last_flags = flags
@@ -512,7 +513,9 @@ def _precision_text(flags: int, coeff_storage: str, Bv: int, Bp: int, fused_lib:
              "(r.r, r.z, p.Ap accumulation, energy estimate): fp64",
              "CG search directions p and all V-cycle (preconditioner) vectors: STORED fp32"]
     if packed:
-        parts.append("V-cycle arithmetic: fp32 (" + ("packed, two samples per lane" if spl2 else "one sample per lane")
+        parts.append("V-cycle arithmetic: fp32 (" + (("packed, two samples per lane" + (
+            " (four in the way-down pass)" if Bp % 256 == 0 and not flags & 512 and coeff_storage == "shared-fp32" else ""))
+            if spl2 else "one sample per lane")
                      + "; coefficients: "
                      + {"shared-fp32": "batch-shared fp32 copies, scalar loads",
                         "fp16-rowsum": "per-sample fp32 diagonal + scaled fp16 couplings, row sums kept"}[coeff_storage]
@@ -720,7 +723,11 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
                                               rdiag32=rdiag32, off16=off16)
         ctx.shift, ctx.wkey, ctx.rdiag32, ctx.off16 = shift, wkey, rdiag32, off16
         if solver.warm_start and not bad:
-            plan.warm_put(("u",) + wkey, x)           # never written again: the next solve starts from a copy
+            # never written by the solver again (the next solve starts from a copy) -- but with layout='node' and no padding
+            # the caller's u IS this tensor, and an in-place edit under no_grad would silently move the next warm start:
+            # keep a private copy then
+            shares = node_major and Bp == B and not plan.has_dirichlet_data
+            plan.warm_put(("u",) + wkey, x.clone() if shares else x)
         info.stop_rules = _rule_counts(eng.last_rule, B) if info.path != "lattice-direct" else {}
         info.flags = eng.last_flags
         info.precision = _precision_text(eng.last_flags, info.coeff_storage, Bv, Bp, int(eng.L.diffhe_lattice_fused_passes()),
@@ -1011,8 +1018,14 @@ def _element_forms(plan: SolvePlan):
         b = torch.stack([y[:, 1] - y[:, 2], y[:, 2] - y[:, 0], y[:, 0] - y[:, 1]], 1)
         c = torch.stack([x[:, 2] - x[:, 1], x[:, 0] - x[:, 2], x[:, 1] - x[:, 0]], 1)
         area = 0.5 * ((x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])).abs()
-        k0 = (b[:, :, None] * b[:, None, :] + c[:, :, None] * c[:, None, :]) / (4.0 * area)[:, None, None]
-        m0 = (area / 9.0)[:, None, None].expand(-1, 3, 3).contiguous()
+        # degenerate triangles are skipped silently, as in the reference (solver.py:120-121), the first-order kernels
+        # (ell.hip) and plan.py: no contribution to K or F instead of a division by ~0
+        keep = (area >= 1e-15)[:, None, None]
+        safe = torch.where(area >= 1e-15, area, torch.ones_like(area))
+        k0 = torch.where(keep, (b[:, :, None] * b[:, None, :] + c[:, :, None] * c[:, None, :]) / (4.0 * safe)[:, None, None],
+                         torch.zeros((), dtype=torch.float64, device=area.device))
+        m0 = torch.where(keep, (safe / 9.0)[:, None, None].expand(-1, 3, 3), torch.zeros((), dtype=torch.float64,
+                                                                                      device=area.device)).contiguous()
     plan.__dict__["_element_forms"] = (el, k0, m0)
     return el, k0, m0
 

@@ -296,6 +296,8 @@ typedef struct diffhe_mg_level {
  *            hierarchy reaches a small coarsest level (multigrid at its textbook rate): the CG step of a batch-shared matrix may
  *            form p.Ap -- the step length only -- with a packed-fp32 stencil, two samples per lane (cgstep2_kernel);
  *            x and r are updated with the exact fp64 A p either way;
+ *            bit 9 (ABI v7): keep the fused PRE pass at two samples per lane (default: four where the batch has whole
+ *            waves of 256 samples and the level has 3 diagonals -- half the vector-memory instructions per byte);
  *            bit 4: stop on `tol` alone.  By default (bit 4 clear, bit 1 set) sample b stops at
  *            |r| <= max(tol |b|, 0.5 u |A_b| |x0_b|), u = 2^-53, |A_b| = 2 scale[b] max_i K_ii: fp64 cannot
  *            bring |b - A x| below ~ u |A| |x|, the recurrence residual keeps falling past that level but the

@@ -776,3 +776,60 @@ def test_batches_of_64_and_192_take_the_fused_kernels_with_one_sample_per_lane(n
         assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U, name
         assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD, name
         assert abs(float(new[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum()), name
+
+
+@pytest.mark.parametrize("name,mesh_fn", [("uniform 256 x 224, non-zero Dirichlet data", lambda: FEMesh.rectangle(256, 224, bc_value=0.3)),
+                                          ("odd sizes 301 x 263 (edge strips in both directions)", lambda: FEMesh.rectangle(301, 263))])
+def test_four_samples_per_lane_pre_pass_agrees_with_the_two_sample_form(name, mesh_fn):
+    """Batches of whole 256-sample waves run the fused way-down pass (two sweeps from zero + residual + restriction) with
+    FOUR samples per lane (16-byte accesses: half the vector-memory instructions per byte); mg={'pre4': 0} keeps two.
+    Same arithmetic per sample: identical iteration counts, answers equal to fp32-preconditioner noise, and the oracle."""
+    mesh = mesh_fn()
+    B, n = 256, mesh.n_nodes
+    gen = torch.Generator().manual_seed(79)
+    kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    new = _run(mesh, kappa, f)
+    two = _run(mesh, kappa, f, mg=dict(pre4=0))
+    assert new[3].path == "lattice-mgpcg" and new[3].not_converged == 0 and two[3].not_converged == 0
+    assert "four in the way-down pass" in new[3].precision and "four in the way-down pass" not in two[3].precision
+    assert new[3].iterations == two[3].iterations and new[3].adj_iterations == two[3].adj_iterations
+    for a, b in zip(new[:3], two[:3]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-11, name
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, 100, B - 1):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, float(kappa[b]), f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=1)
+        assert rel_err(new[0][b].cpu().numpy(), uo) < RTOL_U, name
+        assert rel_err(new[2][b].cpu().numpy(), df) < RTOL_GRAD, name
+        assert abs(float(new[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum()), name
+
+
+def test_hessian_vector_products_on_a_mesh_with_a_degenerate_triangle():
+    """A zero-area triangle is skipped silently by the reference (solver.py:120-121) and by the first-order kernels; the
+    second-order path divided by its area: Hessian-vector products must be finite and equal to those of the
+    same mesh WITHOUT that element (its kappa has no effect: zero gradient, zero Hessian row)."""
+    base = _unstructured(10, 9, seed=12)
+    el = base.elements
+    extra = torch.tensor([[int(el[0, 0]), int(el[0, 1]), int(el[0, 0])]], dtype=el.dtype)       # repeated node: area 0
+    mesh = FEMesh(nodes=base.nodes, elements=torch.cat([el, extra]), dirichlet_nodes=base.dirichlet_nodes)
+    g = torch.Generator().manual_seed(6)
+    m, n = base.n_elements, base.n_nodes
+    k0 = torch.rand(m + 1, generator=g, dtype=T64) + 0.5
+    f0 = torch.rand(n, generator=g, dtype=T64) + 0.5
+    v, w = torch.randn(m + 1, generator=g, dtype=T64), torch.randn(n, generator=g, dtype=T64)
+
+    def second(msh, kk, vv):
+        kap, f = kk.clone().to(DEV).requires_grad_(True), f0.clone().to(DEV).requires_grad_(True)
+        u = DifferentiableFESolver(msh, kap, device=DEV, tol=1e-14)(f)
+        gk, gf = torch.autograd.grad((u ** 3).sum(), (kap, f), create_graph=True)
+        hk, hf = torch.autograd.grad((gk * vv.to(DEV)).sum() + (gf * w.to(DEV)).sum(), (kap, f))
+        return [t.detach().cpu() for t in (gk, gf, hk, hf)]
+
+    with_deg = second(mesh, k0, v)
+    without = second(base, k0[:m], v[:m])
+    for tag, a, b in zip(("dL/dkappa", "dL/df", "H.kappa", "H.f"), with_deg, without):
+        assert bool(torch.isfinite(a).all()), tag
+        a_ = a[:m] if a.shape[0] == m + 1 else a
+        assert rel_err(a_.numpy(), b.numpy()) < 1e-9, (tag, rel_err(a_.numpy(), b.numpy()))
+    assert float(with_deg[0][m]) == 0.0 and float(with_deg[2][m]) == 0.0

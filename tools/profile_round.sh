@@ -13,6 +13,7 @@ cd $R
 st=$(find $out/trace -name "*kernel_stats.csv" | head -1); cp $st $out/kernel_stats.csv
 kt=$(find $out/trace -name "*kernel_trace.csv" | head -1)
 python tools/roofline_table.py $kt > $out/roofline_table.md
+python tools/gap_report.py $kt 40 > $out/step_budget.txt
 python tools/pmc_reduce.py $out/fetch $out/write $out/pmc_traffic.json > $out/pmc_reduce.log
 # the traces themselves are too large to bring back
 rm -rf $out/trace $out/fetch $out/write
