@@ -1451,6 +1451,10 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
     // (Keeping the coarse row in registers between fine rows -- it is loaded three times, 7.5 of a row's 23 loads -- was
     // built and measured in round 4: + 10 live VGPRs spill (100 B of scratch at the 128-VGPR cap of the shared form, 16-100 B
     // at the 168 cap of the per-sample one): POST 1.000 -> 1.034 ms, per-element-field step 213.5 -> 232.0 ms; gpurun_out/r4i.)
+    // ... and kept in a lane-private LDS ring instead (no barrier, no cross-lane traffic: LDS as a second register file
+    // that bypasses the texture addresser; 2.5 instead of 7.5 memory loads per fine row): correct and 1.002 -> 1.417 ms --
+    // LDS and scalar loads share one counter (lgkmcnt), and the waits for the ring serialise the coefficient loads of
+    // both stages (gpurun_out/r4r).  Removed as well.
     VT ce[NCE], ce2[NCE];
 #pragma unroll
     for (int j = 0; j < NCE; ++j) {
