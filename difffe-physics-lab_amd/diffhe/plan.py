@@ -618,6 +618,41 @@ class SolvePlan:
                    "diffhe_ell_assemble_rows(M)")
         self._ell_ready = True
 
+    def closed_boundary_general(self) -> bool:
+        """Every node of the mesh boundary is a Dirichlet node (general meshes, P1: a boundary edge belongs to exactly one
+        triangle; 1D: a boundary node to exactly one element).  The regime in which one scalar kappa per sample may stay
+        FACTORED, K_b = kappa_b K_1 (closed lattices have `closed_boundary`): with Neumann parts the system is
+        ill-conditioned enough for the last-bit difference to the reference's rounded matrix to show.  Cached."""
+        cached = self.__dict__.get("_closed_general")
+        if cached is not None:
+            return cached
+        closed = False
+        if not self.is_p2:
+            el = self._elements
+            is_bc = self.is_bc.cpu().numpy().astype(bool)
+            if self.dim == 1:
+                deg = np.bincount(el.reshape(-1), minlength=self.n)
+                bnodes = np.nonzero(deg == 1)[0]
+            else:
+                e = np.concatenate([el[:, [0, 1]], el[:, [1, 2]], el[:, [2, 0]]])
+                e.sort(axis=1)
+                key = e[:, 0].astype(np.int64) * self.n + e[:, 1]
+                uniq, cnt = np.unique(key, return_counts=True)
+                bkeys = uniq[cnt == 1]
+                bnodes = np.unique(np.concatenate([bkeys // self.n, bkeys % self.n]))
+            closed = bool(len(bnodes) > 0 and is_bc[bnodes].all())
+        self.__dict__["_closed_general"] = closed
+        return closed
+
+    def unit_amg(self, key, build):
+        """The aggregation-multigrid hierarchy (Galerkin coarse operators included) of the UNIT-kappa operator: plan-constant,
+        built once per (smoothed, fp32) by `build()` and shared by every factored solve on this mesh."""
+        cache = self.__dict__.setdefault("_unit_amg", {})
+        with self._lock:
+            if key not in cache:
+                cache[key] = build()
+            return cache[key]
+
     def ensure_amg(self, smoothed: bool = False):
         """Aggregation hierarchy of the general path (diffhe/amg.py), uploaded once per mesh.  smoothed: the
         smoothed-aggregation hierarchy (batch-shared P from the unit-kappa operator, weighted Galerkin lists) instead

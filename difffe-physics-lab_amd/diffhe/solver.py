@@ -56,6 +56,7 @@ class SolveInfo:
     # loads), "fp16-rowsum" (per-sample matrices: fp32 diagonal + scaled fp16 couplings), "fp32" (per-sample plain fp32
     # copies: asked for, or the fallback when a sample's couplings span more than fp16 holds), "fp64" (no copies)
     coeff_storage: str = ""
+    factored: bool = False      # one scalar kappa per sample (or for all) kept as K_b = kappa_b K_1: ONE unit matrix for the batch
     flags: int = 0              # lattice path: the `precond_fp32` word handed to diffhe_lattice_pcg_solve (include/diffhe_hip.h)
     precision: str = ""         # what is stored / computed in which precision in THIS solve, derived from those flags
 
@@ -735,6 +736,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         info.tol_energy = float(mg.get("tol_energy", 0.0) or 0.0)
         ctx.dense = dense
         ctx.factored = factored
+        info.factored = bool(factored)
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
         info.err_est = float(eng.last_est[:B].max())
@@ -745,20 +747,51 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
     else:
         plan.ensure_ell()
         Bp = padded_batch(B)
-        kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp, em=kappa_em)
-        vals, lift = eng.assemble(kdev, kse, ksb, Bv)
-        if reaction:
-            eng.add_reaction([vals], reaction, lattice=False)
-        f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
-        rhs = eng.load_vector(f_nm, lift, Bv, Bp)
-        if load_dev is not None:
-            rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
+        # One scalar kappa per sample on a general mesh whose boundary is closed by Dirichlet data (round 4): kept FACTORED
+        # like on closed lattices, K_b = kappa_b K_1 -- ONE unit matrix for the batch (Bv = 1: the ELL kernels read it as
+        # wave-uniform broadcasts instead of 8 W bytes per node and sample) and the system K_1 x = F_b / kappa_b, whose
+        # solution, residual ratio and adjoint are those of the original one; the aggregation hierarchy and its Galerkin
+        # operators are then plan-constant and built once.  Not with a reaction term (kappa_b K_1 + c M is no multiple of
+        # one matrix), not for operator="assembled", not with Neumann parts (cond * eps, as on lattices).
+        ell_factored = (mode == K_SAMPLE and reaction == 0.0 and solver.operator != "assembled" and not plan.is_p2
+                        and solver.method != "ell-jacobi" and plan.closed_boundary_general())
+        ctx.ell_inv_kappa = None
+        if ell_factored and "fp32" not in solver._amg_user:
+            # the fp32-stored cycle is off by default because high-contrast kappa FIELDS break it; the factored operator
+            # is the unit-kappa matrix of the mesh -- no coefficient contrast at all: 2.33 -> 2.08 ms per iteration, same 39
+            # iterations (jittered 512^2 x 64, gpurun_out/r4v)
+            amg["fp32"] = 1
+        if ell_factored:
+            one = torch.ones(1, dtype=torch.float64, device=plan.device)
+            vals, lift = eng.assemble(one, 0, 0, 1)
+            Bv = 1
+            kpad = torch.ones(Bp, dtype=torch.float64, device=plan.device)
+            kpad[:B] = kappa.detach().to(plan.device, torch.float64).reshape(B)
+            ctx.ell_inv_kappa = 1.0 / kpad
+            f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
+            rhs = eng.load_vector(f_nm, lift, 1, Bp, kpad)          # F_b = M f_b - kappa_b lift_1
+            if load_dev is not None:
+                rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
+            rhs *= ctx.ell_inv_kappa                                 # ... / kappa_b: K_1 x = F_b / kappa_b
+        else:
+            kdev, kse, ksb, Bv = eng.kappa_device(kappa, mode, B, Bp, em=kappa_em)
+            vals, lift = eng.assemble(kdev, kse, ksb, Bv)
+            if reaction:
+                eng.add_reaction([vals], reaction, lattice=False)
+            f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
+            rhs = eng.load_vector(f_nm, lift, Bv, Bp)
+            if load_dev is not None:
+                rhs += eng.to_node_major(load_dev, B, Bp, n, zero_mask=plan.is_bc)
         ctx.amg_hier = None
         if solver.method != "ell-jacobi":
-            amg_levels = plan.ensure_amg(smoothed=bool(amg.get("smoothed", 1)))
+            smoothed = bool(amg.get("smoothed", 1))
+            amg_levels = plan.ensure_amg(smoothed=smoothed)
             if amg.get("scale") is None:
                 amg["scale"] = 1.3 if amg.get("smoothed", 1) else 1.8
-            if amg_levels:                           # at least one coarse level: aggregation-AMG PCG
+            if amg_levels and ell_factored:          # plan-constant hierarchy of the unit operator: built once
+                ctx.amg_hier = plan.unit_amg((smoothed, bool(amg.get("fp32", 0))),
+                                             lambda: eng.amg_setup(vals, 1, bool(amg.get("fp32", 0)), amg_levels))
+            elif amg_levels:                         # at least one coarse level: aggregation-AMG PCG
                 ctx.amg_hier = eng.amg_setup(vals, Bv, bool(amg.get("fp32", 0)), amg_levels)
         if ctx.amg_hier is not None:
             info.path = "ell-amgpcg"
@@ -768,6 +801,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
             x, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
         info.iterations, info.not_converged = its, bad
         info.max_relres = float(relres[:B].max())
+        info.factored = bool(ell_factored)
         u = _from_node_major(eng, x, B, Bp, n, node_major)
         ctx.saved = (vals, x, Bp, Bv, None)
     solver.last_info = info
@@ -860,8 +894,12 @@ def _solve_backward(ctx, gbar, need_k, need_f, need_load=False):
             info.adj_stop_rules = _rule_counts(eng.last_rule, B) if ctx.path != "lattice-direct" else {}
             info.adj_err_est = float(eng.last_est[:B].max())
         elif ctx.path == "ell-amgpcg":    # same preconditioner (and the saved per-sample coarse operators) as forward
+            if getattr(ctx, "ell_inv_kappa", None) is not None:   # factored: lambda_b = K_1^-1 (gbar_b / kappa_b)
+                rhs = rhs * ctx.ell_inv_kappa
             lam, its, bad, relres = eng.amg_pcg(ctx.amg_hier, rhs, Bp, Bv, ctx.amg)
         else:
+            if getattr(ctx, "ell_inv_kappa", None) is not None:
+                rhs = rhs * ctx.ell_inv_kappa
             lam, its, bad, relres = eng.cg(vals, rhs, Bp, Bv)
         info.adj_iterations = its
         info.adj_max_relres = float(relres[:B].max())
@@ -1179,6 +1217,7 @@ class DifferentiableFESolver(nn.Module):
             key, val = item.split("=")
             self.amg[key] = float(val) if key == "scale" else int(val)
         self.amg.update(amg or {})
+        self._amg_user = set((amg or {}).keys()) | {i.split("=")[0] for i in os.environ.get("DIFFHE_AMG", "").split(",") if i}
         # fp32 = 1: the V-cycle (a preconditioner) STORES its vectors in fp32; all arithmetic, the
         # outer CG, its residual, the solution and every dot product stay fp64 (same 1e-10 parity)
         # fmg = 1: the CG starts from a full-multigrid iterate instead of 0 (3 iterations fewer at 1024^2)
@@ -1226,7 +1265,7 @@ class DifferentiableFESolver(nn.Module):
             twin = DifferentiableFESolver(mesh0, self._kappa, device=self._device)
             self.__dict__["_twin"] = twin
         for name in ("tol", "_tol_user", "max_iter", "check_every", "assembly", "method", "chain", "warm_start",
-                     "reaction", "operator", "_mg_user"):
+                     "reaction", "operator", "_mg_user", "_amg_user"):
             setattr(twin, name, getattr(self, name))
         twin.mg, twin.amg, twin.warm_start = dict(self.mg), dict(self.amg), False
         return twin

@@ -833,3 +833,39 @@ def test_hessian_vector_products_on_a_mesh_with_a_degenerate_triangle():
         a_ = a[:m] if a.shape[0] == m + 1 else a
         assert rel_err(a_.numpy(), b.numpy()) < 1e-9, (tag, rel_err(a_.numpy(), b.numpy()))
     assert float(with_deg[0][m]) == 0.0 and float(with_deg[2][m]) == 0.0
+
+
+# ---- general meshes: one scalar kappa per sample stays factored where the boundary is closed (round 4) --------------------
+def test_general_path_keeps_a_per_sample_scalar_factored_on_closed_meshes():
+    """Unstructured mesh, every boundary node Dirichlet, kappa (B,): K_b = kappa_b K_1 -- one unit matrix for the batch
+    (the ELL kernels read it as broadcasts instead of one matrix per sample), the plan-constant aggregation hierarchy built
+    once, K_1 x = F_b / kappa_b solved.  Same answers as operator='assembled' (one matrix per sample in the reference's
+    operation order) far inside the tolerance, same iteration counts, the oracle met; with a Neumann part the mesh is NOT
+    factored (cond * eps, as on lattices)."""
+    mesh = _unstructured(48, 44, seed=21)
+    B, n = 64, mesh.n_nodes
+    gen = torch.Generator().manual_seed(31)
+    kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    fac = _run(mesh, kappa, f)
+    per = _run(mesh, kappa, f, operator="assembled")
+    assert fac[3].path == "ell-amgpcg" and fac[3].factored and not per[3].factored
+    assert fac[3].not_converged == 0 and per[3].not_converged == 0
+    assert abs(fac[3].iterations - per[3].iterations) <= 1 and abs(fac[3].adj_iterations - per[3].adj_iterations) <= 1
+    for a, b in zip(fac[:3], per[:3]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-11
+    again = _run(mesh, kappa, f)                       # the cached hierarchy: bitwise the same answers
+    assert all(torch.equal(a, b) for a, b in zip(fac[:3], again[:3]))
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    for b in (0, B - 1):
+        uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, float(kappa[b]), f[b].numpy(),
+                                            lambda u_: 2 * u_, sparse=True, refine=1)
+        assert rel_err(fac[0][b].cpu().numpy(), uo) < RTOL_U
+        assert rel_err(fac[2][b].cpu().numpy(), df) < RTOL_GRAD
+        assert abs(float(fac[1][b]) - dk.sum()) < RTOL_GRAD * abs(dk.sum())
+    # open boundary: Dirichlet data on part of it only
+    keep = {k: v for i, (k, v) in enumerate(mesh.dirichlet_nodes.items()) if i % 3}
+    open_mesh = FEMesh(nodes=mesh.nodes, elements=mesh.elements, dirichlet_nodes=keep)
+    assert not get_plan(open_mesh, torch.device(DEV)).closed_boundary_general()
+    assert get_plan(mesh, torch.device(DEV)).closed_boundary_general()
+    assert not _run(open_mesh, kappa, f)[3].factored

@@ -23,10 +23,11 @@ kappa = torch.from_numpy(rng.uniform(0.5, 2.0, B)).cuda()
 f = torch.ones(B, mesh.n_nodes, dtype=torch.float64, device="cuda")
 for gamma in gammas:
     for scale in scales:
-        s = DifferentiableFESolver(mesh, kappa, device="cuda", method="ell")
+        s = DifferentiableFESolver(mesh, kappa, device="cuda", method="ell", operator=os.environ.get("AMG_BENCH_OPERATOR", "auto"))
         s.amg.update(gamma=gamma, scale=scale)
         print("pass_bytes", mesh.n_nodes * B * 8)
         t0 = time.time(); u = s(f); torch.cuda.synchronize(); t_first = time.time() - t0
         t0 = time.time(); u = s(f); torch.cuda.synchronize(); t = time.time() - t0
         print(f"N={N} B={B} gamma={gamma} scale={scale}: its={s.last_info.iterations} relres={s.last_info.max_relres:.2e} path={s.last_info.path} "
-              f"first={t_first:.2f}s steady={t*1e3:.1f} ms  ({B/t:.1f} solves/s)", flush=True)
+              f"first={t_first:.2f}s steady={t*1e3:.1f} ms  ({B/t:.1f} solves/s) factored={s.last_info.factored} "
+              f"ms_per_iteration={t*1e3/max(s.last_info.iterations,1):.3f}", flush=True)
