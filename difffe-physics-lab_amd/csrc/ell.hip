@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
 // Seven entry kinds per row in the order (0, +1, +W, +nx, -1, -W, -nx); the first nd are stored, the others only feed
 // the Dirichlet lift.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __restrict__ local,
+// `local` is (9, m), or -- compact form, emask = 1, lm = 2 -- (9, 2): one unit matrix per triangle ORIENTATION (element
+// parity) of a lattice whose triangles are congruent bit for bit (FEMesh.rectangle with exactly representable spacing:
+// the bench mesh).  Same values, same order; the 18 wave-uniform loads per node then hit a 144-byte table instead of a
+// (9, m) array (151 MB at 1024^2, which lives in the Infinity Cache at best): 6.7 -> see DESIGN section 6, round 4.
+__global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __restrict__ local, i64 lm, i64 emask,
                                                                 const double* __restrict__ kappa, i64 kse, i64 ksb,
                                                                 const unsigned char* __restrict__ is_bc,
                                                                 const double* __restrict__ g, double* __restrict__ vals,
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __r
   const NodeMap nm = node_map(Bv);
   if (nm.b >= Bv) return;
   const int W = nx + 1;
-  const i64 n = (i64)W * (ny + 1), m = 2 * (i64)nx * ny;
+  const i64 n = (i64)W * (ny + 1);
   const i64 kb = (i64)nm.b * ksb;
   for (int i = nm.node0; i < n; i += nm.stride) {
     const int r = i / W, c = i - r * W;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __r
     const double kD = hDE ? (kappa ? kappa[eD * kse + kb] : 1.0) : 0.0;
     const double kE = hDE ? (kappa ? kappa[eE * kse + kb] : 1.0) : 0.0;
     const double kF = hF ? (kappa ? kappa[eF * kse + kb] : 1.0) : 0.0;
-    auto loc = [&](int pq, i64 e) -> double { return local[(i64)pq * m + e]; };
+    auto loc = [&](int pq, i64 e) -> double { return local[(i64)pq * lm + (e & emask)]; };
     const bool row_bc = is_bc && is_bc[i];
     double lfv = 0.0;
     // entry kinds: offsets and contribution lists (mask, element, kappa, local entry), increasing element id
@@ -948,17 +952,19 @@ extern "C" int diffhe_ell_assemble_rows(const double* local, const double* kappa
   return diffhe::check_launch();
 }
 
-extern "C" int diffhe_lattice_assemble_rows(const double* local, const double* kappa, long long kappa_se,
-                                            long long kappa_sb, const unsigned char* is_bc, const double* g,
-                                            double* vals, double* lift, int nx, int ny, int nd, int Bv, void* stream) {
+extern "C" int diffhe_lattice_assemble_rows(const double* local, int local_compact, const double* kappa,
+                                            long long kappa_se, long long kappa_sb, const unsigned char* is_bc,
+                                            const double* g, double* vals, double* lift, int nx, int ny, int nd, int Bv,
+                                            void* stream) {
   if (!local || !vals || nx < 1 || ny < 1 || nd < 3 || nd > 4) return DIFFHE_E_BADARG;
   if (is_bc && !g) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bv)) return DIFFHE_E_BATCHPAD;
   const long long n = (long long)(nx + 1) * (ny + 1), m = 2LL * nx * ny;
   if (n > 2147483647LL) return DIFFHE_E_BADARG;
   diffhe::account(8.0 * Bv * ((double)nd * n + (lift ? n : 0) + ((kappa && kappa_se) ? m : 0)));
-  hipLaunchKernelGGL(lattice_assemble_kernel, diffhe::node_grid((int)n, Bv), dim3(256), 0, (hipStream_t)stream, local, kappa,
-                     kappa_se, kappa_sb, is_bc, g, vals, lift, nx, ny, nd, Bv);
+  hipLaunchKernelGGL(lattice_assemble_kernel, diffhe::node_grid((int)n, Bv), dim3(256), 0, (hipStream_t)stream, local,
+                     (i64)(local_compact ? 2 : m), (i64)(local_compact ? 1 : -1), kappa, kappa_se, kappa_sb, is_bc, g, vals,
+                     lift, nx, ny, nd, Bv);
   return diffhe::check_launch();
 }
 

@@ -214,8 +214,9 @@ struct Extra {
   const double* addv;       // M_APPLY, F_NONE: batch-shared (n) vector added to A x (may be NULL)
   float* r32;               // M_RESID, F_NONE, fp64 vectors: also store the residual rounded to fp32 (may be NULL)
   const double* rscale;     //   ... multiplied by this per-sample power of two first (may be NULL: 1)
-  const double* sub;        // M_APPLY, F_NONE: y = A x - sub_scale[b] * sub[i], sub batch-shared (n) (may be NULL)
+  const double* sub;        // M_APPLY, F_NONE: y = A x - sub_scale[b] * sub[i], sub batch-shared (n) (may be NULL) ...
   const double* sub_scale;  //   per-sample factor of `sub` (NULL: 1)
+  int sub_pb;               //   ... or, sub_pb != 0, one value per sample: sub is (n, Bp) (the Dirichlet lift of per-sample matrices)
   const unsigned char* mask;  // M_APPLY, F_NONE: rows with mask[i] != 0 are stored as 0 (may be NULL)
   int dot_bx;               // M_RESID, F_NONE: the partial sums hold b.x (energy of the iterate) instead of r.r ...
   double* part2;            //   ... and these (same layout as `part`) x.(A x)
@@ -393,7 +394,7 @@ __device__ __forceinline__ double strip_body(const Level& L, double sb, const TV
         double y = Ax;
         if (FUSE == F_NONE && (ex.sub || ex.mask)) {  // load vector of a lattice mesh: F = M f - lift, 0 on Dirichlet rows
           const i64 ig = (i64)row * W + c0w + k;
-          if (ex.sub) y -= sub_fac * ex.sub[ig];
+          if (ex.sub) y -= sub_fac * (ex.sub_pb ? (ex.sub + ig * Bp)[lb] : ex.sub[ig]);
           if (ex.mask && ex.mask[ig]) y = 0.0;
         }
         if (po) {
@@ -3688,9 +3689,12 @@ extern "C" int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double*
   L.nx = nx; L.ny = ny; L.W = nx + 1; L.n = (nx + 1) * (ny + 1); L.nd = nd; L.v = vals; L.v32 = nullptr; L.bc = nullptr;
   L.rd32 = nullptr; L.mk32 = nullptr; L.o16 = nullptr; L.osc = nullptr;
   const StripGeom g = strip_geom(L, Bp);
-  if (g.use && (!sub || sub_B == 1)) {
+  if (g.use) {
     Extra ex{};
     ex.sub = sub; ex.sub_scale = sub_scale; ex.mask = mask;
+    ex.sub_pb = (sub && sub_B != 1) ? 1 : 0;   // per-sample lift: read in the strip pass too (it used to fall to the
+                                               // gather kernel below: 2.67 instead of ~1.4 ms at 1024^2 x 256)
+    if (ex.sub_pb) diffhe::account(8.0 * (double)L.n * Bp);
     launch_strip<double, M_APPLY, false>(L, 1, nullptr, x, (const double*)nullptr, y, 0.0, 0.0, nullptr, Bp, g,
                                          (hipStream_t)stream, ex);
     return diffhe::check_launch();
@@ -3719,8 +3723,8 @@ extern "C" int diffhe_lattice_smooth(const diffhe_mg_level* level, int Bv, const
 // column) instead of once per incident element (6x), k0 arrives as scalar loads, dk leaves as 512 B rows.
 // 32 B per node and sample of algorithmic traffic (lambda, u, two dk): the element-loop kernel ran it at 1.2 TB/s.
 constexpr int kGradCols = 4;
-__global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny, const double* __restrict__ k0,
-                                                                  const double* __restrict__ lam,
+__global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny, const double* __restrict__ k0, i64 lm,
+                                                                  i64 emask, const double* __restrict__ lam,
                                                                   const double* __restrict__ u,
                                                                   const double* __restrict__ g, double* __restrict__ dk,
                                                                   int Bp, int ncb, int TR) {
@@ -3735,7 +3739,6 @@ __global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny,
   const int r1 = (r0 + TR < ny) ? r0 + TR : ny;        // quad rows r0 .. r1 - 1
   if (c0 >= nx || r0 >= r1) return;
   const int W = nx + 1;
-  const i64 m = 2LL * nx * ny;
   int dc[GW + 1];                                       // node columns c0 .. c0 + GW, clamped at the right edge
 #pragma unroll
   for (int j = 0; j < GW + 1; ++j) dc[j] = (c0 + j < W) ? j : W - 1 - c0;
@@ -3767,7 +3770,7 @@ __global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny,
 #pragma unroll
         for (int p_ = 0; p_ < 3; ++p_)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * m + e] * uq[q];
+          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * lm + (e & emask)] * uq[q];
         (dk + e * Bp)[lb] = -acc;
       }
       // T1 = [b, c, d]: b = (r, c + 1), c = (r + 1, c + 1), d = (r + 1, c)
@@ -3777,7 +3780,7 @@ __global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny,
 #pragma unroll
         for (int p_ = 0; p_ < 3; ++p_)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * m + e + 1] * uq[q];
+          for (int q = 0; q < 3; ++q) acc += lp[p_] * k0[(i64)(p_ * 3 + q) * lm + ((e + 1) & emask)] * uq[q];
         (dk + (e + 1) * Bp)[lb] = -acc;
       }
     }
@@ -3792,8 +3795,8 @@ __global__ __launch_bounds__(256) void lattice_grad_kappa_kernel(int nx, int ny,
   }
 }
 
-extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u,
-                                         const double* g, double* dk, int Bp, void* stream) {
+extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, int k0_compact, const double* lam,
+                                         const double* u, const double* g, double* dk, int Bp, void* stream) {
   if (!k0 || !lam || !u || !dk || nx < 2 || ny < 2) return DIFFHE_E_BADARG;
   if (!diffhe::valid_batch_pad(Bp)) return DIFFHE_E_BATCHPAD;
   if (Bp < kWave) return DIFFHE_E_TOOBIG;              // small batches: diffhe_p1_grad_kappa
@@ -3805,8 +3808,9 @@ extern "C" int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const
   const int TR = (ny + nrc - 1) / nrc;
   nrc = (ny + TR - 1) / TR;
   diffhe::account(32.0 * (double)(nx + 1) * (ny + 1) * Bp);   // lambda, u once per node; two dk per node
-  hipLaunchKernelGGL(lattice_grad_kappa_kernel, dim3(ncb * nrc, gy), dim3(256), 0, (hipStream_t)stream, nx, ny, k0, lam, u, g,
-                     dk, Bp, ncb, TR);
+  const i64 mm = 2LL * nx * ny;
+  hipLaunchKernelGGL(lattice_grad_kappa_kernel, dim3(ncb * nrc, gy), dim3(256), 0, (hipStream_t)stream, nx, ny, k0,
+                     (i64)(k0_compact ? 2 : mm), (i64)(k0_compact ? 1 : -1), lam, u, g, dk, Bp, ncb, TR);
   return diffhe::check_launch();
 }
 

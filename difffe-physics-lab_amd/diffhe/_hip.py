@@ -45,7 +45,7 @@ SIGNATURES = {
                                     _P]),
     "diffhe_p1_element_integrals": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "diffhe_ell_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "diffhe_lattice_assemble_rows": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "diffhe_lattice_assemble_rows": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_rows_ref": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_assemble_atomic": (_I, [_P, _P, _I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P]),
     "diffhe_ell_apply_dirichlet": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "diffhe_lattice_restrict_kappa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "diffhe_lattice_pack_h16": (_I, [_LV, _I, _P, _P, _P, _P, _P]),
     "diffhe_lattice_max_diag": (_I, [_LV, _I, _P, _P]),
-    "diffhe_lattice_grad_kappa": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "diffhe_lattice_grad_kappa": (_I, [_I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "diffhe_grad_kappa_blocks": (_I, [_I, _I]),
     "diffhe_p1_grad_kappa": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "diffhe_p1_grad_kappa_shared": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -405,6 +405,18 @@ class LatticeLevel:
             self._mask32 = (1 - self.is_bc.to(torch.float32)).contiguous()
         return self._mask32
 
+    def compact(self, which: str):
+        """(9, 2) tensor = the element matrices `which` ("k0" | "k0ref") of the two triangle orientations, if those of all
+        even and of all odd elements are BITWISE equal (a lattice with exactly representable spacing, e.g. N a power of two
+        on the unit square: the bench mesh) -- what diffhe_lattice_assemble_rows / diffhe_lattice_grad_kappa take in
+        compact form; None otherwise (jittered or skewed lattices, spacings with rounding).  Same numbers either way."""
+        cache = self.__dict__.setdefault("_compact", {})
+        if which not in cache:
+            t = self.k0 if which == "k0" else self.k0ref()
+            same = bool((t[:, 0::2] == t[:, 0:1]).all()) and bool((t[:, 1::2] == t[:, 1:2]).all())
+            cache[which] = t[:, :2].contiguous() if same else None
+        return cache[which]
+
     def zero_g(self):
         """Dirichlet values of a coarse level: corrections vanish there."""
         if self._zero_g is None:

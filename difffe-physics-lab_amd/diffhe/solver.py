@@ -289,7 +289,7 @@ class _Engine:
                 # difference of the entries shows as 4e-10 in u, which is why per-sample scalars are left unfactored on
                 # them, `closed_` in _solve_forward) -- they, per-sample SCALARS that are not factored, and
                 # operator="assembled" keep the bit-identical order below
-                self._lattice_rows(lev, lev.k0ref(), kl, kse, ksb, p.g, v, lf, Bv, st)
+                self._lattice_rows(lev, "k0ref", kl, kse, ksb, p.g, v, lf, Bv, st)
             elif li == 0 and kl is not None:   # the operator the solution is defined by: reference operation order
                 _hip.check(L.diffhe_ell_assemble_rows_ref(_hip.ptr(lev.tnum), _hip.ptr(lev.den), _hip.ptr(kl), kse, ksb,
                                                           _hip.ptr(lev.ent_ptr), _hip.ptr(lev.contrib),
@@ -297,21 +297,25 @@ class _Engine:
                                                           _hip.ptr(lev.is_bc), _hip.ptr(p.g), _hip.ptr(v), _hip.ptr(lf),
                                                           lev.n, lev.m, 7, Bv, st), "diffhe_ell_assemble_rows_ref(lattice)")
             else:
-                self._lattice_rows(lev, lev.k0, kl, kse, ksb, p.g if li == 0 else lev.zero_g(), v, lf, Bv, st)
+                self._lattice_rows(lev, "k0", kl, kse, ksb, p.g if li == 0 else lev.zero_g(), v, lf, Bv, st)
             vals.append(v)
             if li == 0:
                 lift = lf
         return vals, Bv, scale, lift, scale
 
-    def _lattice_rows(self, lev, local, kl, kse, ksb, g, v, lf, Bv, st):
+    def _lattice_rows(self, lev, which, kl, kse, ksb, g, v, lf, Bv, st):
         """kappa * k0 gathered into the symmetric diagonals of a lattice level (+ the Dirichlet lift).  The lattice form of
         the gather (contribution lists written into the kernel, each kappa_e read once per node) gives bitwise the values
         of the list-driven kernel (tests/test_robustness.py); DIFFHE_LATTICE_ASSEMBLE=0 keeps the latter."""
         L = self.L
+        local = lev.k0 if which == "k0" else lev.k0ref()
         if os.environ.get("DIFFHE_LATTICE_ASSEMBLE", "1") != "0":
-            _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(local), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.is_bc),
-                                                      _hip.ptr(g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd, Bv,
-                                                      st), "diffhe_lattice_assemble_rows")
+            # congruent triangles (bit for bit): one (9, 2) table instead of the (9, m) array -- same values
+            small = lev.compact(which) if os.environ.get("DIFFHE_COMPACT_K0", "1") != "0" else None
+            _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(small if small is not None else local),
+                                                      1 if small is not None else 0, _hip.ptr(kl), kse, ksb,
+                                                      _hip.ptr(lev.is_bc), _hip.ptr(g), _hip.ptr(v), _hip.ptr(lf), lev.nx,
+                                                      lev.ny, lev.nd, Bv, st), "diffhe_lattice_assemble_rows")
         else:
             _hip.check(L.diffhe_ell_assemble_rows(_hip.ptr(local), _hip.ptr(kl), kse, ksb, _hip.ptr(lev.ent_ptr),
                                                   _hip.ptr(lev.contrib), _hip.ptr(lev.cols), _hip.ptr(lev.store_slot),
@@ -477,7 +481,9 @@ class _Engine:
             # lattice mesh, per-element gradient of every sample: strip pass (each nodal value read once per wave)
             lev = p.levels[0]
             dk_e = torch.empty((p.m, Bp), dtype=torch.float64, device=p.device)
-            _hip.check(L.diffhe_lattice_grad_kappa(lev.nx, lev.ny, _hip.ptr(lev.k0), _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
+            small = lev.compact("k0") if os.environ.get("DIFFHE_COMPACT_K0", "1") != "0" else None
+            _hip.check(L.diffhe_lattice_grad_kappa(lev.nx, lev.ny, _hip.ptr(small if small is not None else lev.k0),
+                                                   1 if small is not None else 0, _hip.ptr(lam), _hip.ptr(x), _hip.ptr(p.g),
                                                    _hip.ptr(dk_e), Bp, _stream(p.device)), "diffhe_lattice_grad_kappa")
             return dk_e, None
         nblk = L.diffhe_grad_kappa_blocks(p.m, Bp)

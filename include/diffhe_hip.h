@@ -136,11 +136,12 @@ int diffhe_ell_assemble_rows(const double* local, const double* kappa, long long
  * contributions of the seven entry kinds (0, +1, +W, +nx, -1, -W, -nx; the first `nd` stored as symmetric diagonals
  * (nd, n, Bv), the rest feeding the Dirichlet lift) are written into the kernel in the element order of the
  * reference's loops (solver.py:137-140) -- bitwise the values of diffhe_ell_assemble_rows with the lattice lists, each
- * kappa_e read once per node.  local: (9, m) unit element matrices; kappa (optional) strided by kappa_se per element
- * and kappa_sb per sample. */
-int diffhe_lattice_assemble_rows(const double* local, const double* kappa, long long kappa_se, long long kappa_sb,
-                                 const unsigned char* is_bc, const double* g, double* vals, double* lift, int nx, int ny,
-                                 int nd, int Bv, void* stream);
+ * kappa_e read once per node.  local: (9, m) unit element matrices, or -- local_compact != 0, ABI v7 -- (9, 2): one matrix
+ * per triangle orientation (element parity) of a lattice whose triangles are congruent bit for bit (the caller has
+ * compared the columns); kappa (optional) strided by kappa_se per element and kappa_sb per sample. */
+int diffhe_lattice_assemble_rows(const double* local, int local_compact, const double* kappa, long long kappa_se,
+                                 long long kappa_sb, const unsigned char* is_bc, const double* g, double* vals,
+                                 double* lift, int nx, int ny, int nd, int Bv, void* stream);
 /* The same gather assembly in the REFERENCE'S OPERATION ORDER: tnum (npe*npe, m) holds t = b_p b_q + c_p c_q (2D;
  * +-1 in 1D), den (m) holds 4 area (2D; h in 1D), and every contribution is (kappa * t) / den with each operation
  * rounded on its own (no contracted multiply-adds, a true division), added in element order -- solver.py:88-92,
@@ -377,9 +378,10 @@ int diffhe_lattice_apply_shared(int nx, int ny, int nd, const double* vals, cons
 /* dk[e, b] = - sum_{p,q} lambda[node_p, b] k0[p*3+q, e] (u[node_q, b] + g[node_q]) for every element of a LATTICE mesh
  * (FEMesh.rectangle connectivity) and every sample: the per-element gradient of diffhe_p1_grad_kappa as a strip pass
  * (each nodal value loaded once per wave instead of once per incident element).  k0 (9, m) unit-kappa element
- * matrices, lam / u (n, Bp), g (n) or NULL, dk (m, Bp).  DIFFHE_E_TOOBIG for Bp < 64 (use diffhe_p1_grad_kappa). */
-int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, const double* lam, const double* u, const double* g,
-                              double* dk, int Bp, void* stream);
+ * matrices (k0_compact != 0, ABI v7: (9, 2), one per triangle orientation, as in diffhe_lattice_assemble_rows), lam / u
+ * (n, Bp), g (n) or NULL, dk (m, Bp).  DIFFHE_E_TOOBIG for Bp < 64 (use diffhe_p1_grad_kappa). */
+int diffhe_lattice_grad_kappa(int nx, int ny, const double* k0, int k0_compact, const double* lam, const double* u,
+                              const double* g, double* dk, int Bp, void* stream);
 /* Compact coefficient copies of a per-sample matrix for the fp32-stored V-cycle (diffhe_mg_level.vals32 / offdiag16):
  * diag32 (n, Bv) fp32, offdiag16 (nd - 1, n, Bv) fp16 of vals / offdiag_scales[b] (per-sample powers of two >= the
  * sample's max free-row diagonal, device array of Bv doubles); the diagonal absorbs the rounding differences of its row's

@@ -391,7 +391,7 @@ def test_lattice_assembly_without_lists_is_bitwise_the_list_driven_gather(mesh_f
                                                       _hip.ptr(lev.is_bc), _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.n,
                                                       lev.m, 7, Bv, st), "lists")
             else:
-                _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(lev.k0), _hip.ptr(kap), kse, ksb, _hip.ptr(lev.is_bc),
+                _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(lev.k0), 0, _hip.ptr(kap), kse, ksb, _hip.ptr(lev.is_bc),
                                                           _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd,
                                                           Bv, st), "lattice")
             torch.cuda.synchronize()
@@ -869,3 +869,42 @@ def test_general_path_keeps_a_per_sample_scalar_factored_on_closed_meshes():
     assert not get_plan(open_mesh, torch.device(DEV)).closed_boundary_general()
     assert get_plan(mesh, torch.device(DEV)).closed_boundary_general()
     assert not _run(open_mesh, kappa, f)[3].factored
+
+
+def test_compact_element_matrices_of_congruent_lattices_give_bitwise_the_same_operator_and_gradient():
+    """FEMesh.rectangle(64, 32) on the unit square (spacings 2^-6, 2^-5: exact): all triangles of one orientation have
+    bitwise the same unit stiffness matrix, and the per-sample assembly / the per-element gradient read a (9, 2) table
+    instead of the (9, m) arrays (plan.LatticeLevel.compact).  Same numbers, same order: bitwise equal matrices, lift and
+    gradients; a lattice whose spacing is not exactly representable has no compact form."""
+    from diffhe import _hip
+    from diffhe.plan import _stream
+    mesh = FEMesh.rectangle(64, 32, bc_value=0.4)
+    plan = get_plan(mesh, torch.device(DEV))
+    lev = plan.levels[0]
+    assert lev.compact("k0") is not None and lev.compact("k0ref") is not None
+    assert get_plan(FEMesh.rectangle(60, 33), torch.device(DEV)).levels[0].compact("k0ref") is None
+    L, st = _hip.lib(), _stream(plan.device)
+    Bv = 64
+    kap = torch.exp(0.3 * torch.randn(lev.m, Bv, dtype=T64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)))
+    out = []
+    for which in ("k0", "k0ref"):
+        full = lev.k0 if which == "k0" else lev.k0ref()
+        pair = []
+        for tab, flag in ((full, 0), (lev.compact(which), 1)):
+            v = torch.full((lev.nd, lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            lf = torch.full((lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(tab), flag, _hip.ptr(kap), Bv, 1, _hip.ptr(lev.is_bc),
+                                                      _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd, Bv,
+                                                      st), "assemble")
+            pair.append((v, lf))
+        torch.cuda.synchronize()
+        assert torch.equal(pair[0][0], pair[1][0]) and torch.equal(pair[0][1], pair[1][1]), which
+    lam = torch.randn(lev.n, Bv, dtype=T64, device=DEV)
+    u = torch.randn(lev.n, Bv, dtype=T64, device=DEV)
+    for tab, flag in ((lev.k0, 0), (lev.compact("k0"), 1)):
+        dk = torch.full((lev.m, Bv), float("nan"), dtype=T64, device=DEV)
+        _hip.check(L.diffhe_lattice_grad_kappa(lev.nx, lev.ny, _hip.ptr(tab), flag, _hip.ptr(lam), _hip.ptr(u), _hip.ptr(plan.g),
+                                               _hip.ptr(dk), Bv, st), "grad")
+        out.append(dk)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and bool(torch.isfinite(out[0]).all())
