@@ -117,6 +117,48 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(
 // Seven entry kinds per row in the order (0, +1, +W, +nx, -1, -W, -nx); the first nd are stored, the others only feed
 // the Dirichlet lift.
 // ---------------------------------------------------------------------------------------
+// The seven entries of node i's row (and its Dirichlet lift) from the kappa of its six triangles: shared by the
+// node-per-wave kernel and the strip kernel below, so that both produce bitwise the same values.
+__device__ __forceinline__ void lattice_node_entries(const double* __restrict__ local, i64 lm, i64 emask, double kA,
+                                                     double kB, double kC, double kD, double kE, double kF, i64 eA, i64 eB,
+                                                     i64 eC, i64 eD, i64 eE, i64 eF, bool up, bool dn, bool lf, bool rt,
+                                                     int i, int W, int nx, i64 n, int nd,
+                                                     const unsigned char* __restrict__ is_bc,
+                                                     const double* __restrict__ g, double* __restrict__ vals,
+                                                     double* __restrict__ lift, int Bv, int b) {
+#pragma clang fp contract(off)
+    const bool hA = dn && lf, hBC = dn && rt, hDE = up && lf, hF = up && rt;
+    auto loc = [&](int pq, i64 e) -> double { return local[(i64)pq * lm + (e & emask)]; };
+    const bool row_bc = is_bc && is_bc[i];
+    double lfv = 0.0;
+    // entry kinds: offsets and contribution lists (mask, element, kappa, local entry), increasing element id
+#define CONTRIB(mask_, k_, pq_, e_) if (mask_) v = fma((k_), loc((pq_), (e_)), v)
+#define ENTRY(kind_, off_, any_, BODY)                                                        \
+    {                                                                                         \
+      const int store = (kind_) < nd ? (kind_) : -1;                                          \
+      const i64 j = (any_) ? (i64)i + (off_) : (i64)i;                                        \
+      const bool col_bc = is_bc && j != i && is_bc[j];                                        \
+      if (!(store < 0 && (row_bc || !col_bc))) {                                              \
+        double v = 0.0;                                                                       \
+        BODY                                                                                  \
+        if (row_bc) v = ((kind_) == 0) ? 1.0 : 0.0;                                           \
+        else if (col_bc) { lfv += v * g[j]; v = 0.0; }                                        \
+        if (store >= 0) vals[((i64)store * n + i) * Bv + b] = v;                           \
+      }                                                                                       \
+    }
+    ENTRY(0, 0, true, CONTRIB(hA, kA, 4, eA); CONTRIB(hBC, kB, 8, eB); CONTRIB(hBC, kC, 8, eC); CONTRIB(hDE, kD, 4, eD);
+          CONTRIB(hDE, kE, 0, eE); CONTRIB(hF, kF, 0, eF);)
+    ENTRY(1, 1, rt, CONTRIB(rt && dn, kC, 7, eC); CONTRIB(rt && up, kF, 1, eF);)
+    ENTRY(2, W, up, CONTRIB(up && lf, kE, 1, eE); CONTRIB(up && rt, kF, 2, eF);)
+    ENTRY(3, nx, up && lf, CONTRIB(up && lf, kD, 5, eD); CONTRIB(up && lf, kE, 2, eE);)
+    ENTRY(4, -1, lf, CONTRIB(lf && dn, kA, 5, eA); CONTRIB(lf && up, kD, 3, eD);)
+    ENTRY(5, -W, dn, CONTRIB(dn && lf, kA, 3, eA); CONTRIB(dn && rt, kB, 6, eB);)
+    ENTRY(6, -nx, dn && rt, CONTRIB(dn && rt, kB, 7, eB); CONTRIB(dn && rt, kC, 6, eC);)
+#undef ENTRY
+#undef CONTRIB
+    if (lift) lift[(i64)i * Bv + b] = lfv;
+}
+
 // `local` is (9, m), or -- compact form, emask = 1, lm = 2 -- (9, 2): one unit matrix per triangle ORIENTATION (element
 // parity) of a lattice whose triangles are congruent bit for bit (FEMesh.rectangle with exactly representable spacing:
 // the bench mesh).  Same values, same order; the 18 wave-uniform loads per node then hit a 144-byte table instead of a
@@ -146,35 +188,63 @@ __global__ __launch_bounds__(256) void lattice_assemble_kernel(const double* __r
     const double kD = hDE ? (kappa ? kappa[eD * kse + kb] : 1.0) : 0.0;
     const double kE = hDE ? (kappa ? kappa[eE * kse + kb] : 1.0) : 0.0;
     const double kF = hF ? (kappa ? kappa[eF * kse + kb] : 1.0) : 0.0;
-    auto loc = [&](int pq, i64 e) -> double { return local[(i64)pq * lm + (e & emask)]; };
-    const bool row_bc = is_bc && is_bc[i];
-    double lfv = 0.0;
-    // entry kinds: offsets and contribution lists (mask, element, kappa, local entry), increasing element id
-#define CONTRIB(mask_, k_, pq_, e_) if (mask_) v = fma((k_), loc((pq_), (e_)), v)
-#define ENTRY(kind_, off_, any_, BODY)                                                        \
-    {                                                                                         \
-      const int store = (kind_) < nd ? (kind_) : -1;                                          \
-      const i64 j = (any_) ? (i64)i + (off_) : (i64)i;                                        \
-      const bool col_bc = is_bc && j != i && is_bc[j];                                        \
-      if (!(store < 0 && (row_bc || !col_bc))) {                                              \
-        double v = 0.0;                                                                       \
-        BODY                                                                                  \
-        if (row_bc) v = ((kind_) == 0) ? 1.0 : 0.0;                                           \
-        else if (col_bc) { lfv += v * g[j]; v = 0.0; }                                        \
-        if (store >= 0) vals[((i64)store * n + i) * Bv + nm.b] = v;                           \
-      }                                                                                       \
+    lattice_node_entries(local, lm, emask, kA, kB, kC, kD, kE, kF, eA, eB, eC, eD, eE, eF, up, dn, lf, rt, i, W, nx, n, nd,
+                         is_bc, g, vals, lift, Bv, nm.b);
+  }
+}
+
+// The same assembly as a STRIP pass (per-sample kappa fields on big levels): a wave owns RW node columns x 64 samples
+// and marches down the node rows with the kappa of two quad rows in registers -- every kappa_e is loaded once per wave
+// and quad row (2 (RW + 1) loads per RW nodes) instead of once per incident node (6 per node).  Same per-node arithmetic
+// (lattice_node_entries): bitwise the values of lattice_assemble_kernel.
+constexpr int kAsmCols = 4;
+__global__ __launch_bounds__(256) void lattice_assemble_strip_kernel(const double* __restrict__ local, i64 lm, i64 emask,
+                                                                      const double* __restrict__ kappa, i64 kse, i64 ksb,
+                                                                      const unsigned char* __restrict__ is_bc,
+                                                                      const double* __restrict__ g,
+                                                                      double* __restrict__ vals, double* __restrict__ lift,
+                                                                      int nx, int ny, int nd, int Bv, int ncb, int TR) {
+  constexpr int RW = kAsmCols;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y * kWave + lane;
+  const int rc = blockIdx.x / ncb, cb = blockIdx.x - rc * ncb;
+  const int c0 = (cb * 4 + wave) * RW;              // first node column
+  const int r0 = rc * TR;
+  const int r1 = (r0 + TR < ny + 1) ? r0 + TR : ny + 1;
+  if (c0 > nx || r0 >= r1) return;
+  const int W = nx + 1;
+  const i64 n = (i64)W * (ny + 1);
+  const i64 kb = (i64)b * ksb;
+  // kappa of quad row qr on the quad columns c0 - 1 + j, both triangles; 0 outside the grid (never used there: masks)
+  double lo[RW + 1][2], hi[RW + 1][2];
+  auto load_quads = [&](int qr, double (*dst)[2]) {
+#pragma unroll
+    for (int j = 0; j < RW + 1; ++j) {
+      const int qc = c0 - 1 + j;
+      const bool ok = qr >= 0 && qr < ny && qc >= 0 && qc < nx;
+      const i64 e = 2 * ((i64)qr * nx + qc);
+      dst[j][0] = ok ? kappa[e * kse + kb] : 0.0;
+      dst[j][1] = ok ? kappa[(e + 1) * kse + kb] : 0.0;
     }
-    ENTRY(0, 0, true, CONTRIB(hA, kA, 4, eA); CONTRIB(hBC, kB, 8, eB); CONTRIB(hBC, kC, 8, eC); CONTRIB(hDE, kD, 4, eD);
-          CONTRIB(hDE, kE, 0, eE); CONTRIB(hF, kF, 0, eF);)
-    ENTRY(1, 1, rt, CONTRIB(rt && dn, kC, 7, eC); CONTRIB(rt && up, kF, 1, eF);)
-    ENTRY(2, W, up, CONTRIB(up && lf, kE, 1, eE); CONTRIB(up && rt, kF, 2, eF);)
-    ENTRY(3, nx, up && lf, CONTRIB(up && lf, kD, 5, eD); CONTRIB(up && lf, kE, 2, eE);)
-    ENTRY(4, -1, lf, CONTRIB(lf && dn, kA, 5, eA); CONTRIB(lf && up, kD, 3, eD);)
-    ENTRY(5, -W, dn, CONTRIB(dn && lf, kA, 3, eA); CONTRIB(dn && rt, kB, 6, eB);)
-    ENTRY(6, -nx, dn && rt, CONTRIB(dn && rt, kB, 7, eB); CONTRIB(dn && rt, kC, 6, eC);)
-#undef ENTRY
-#undef CONTRIB
-    if (lift) lift[(i64)i * Bv + nm.b] = lfv;
+  };
+  load_quads(r0 - 1, lo);
+  for (int r = r0; r < r1; ++r) {
+    load_quads(r, hi);
+    const bool up = r < ny, dn = r >= 1;
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int c = c0 + k;
+      if (c > nx) continue;
+      const bool lf = c >= 1, rt = c < nx;
+      const i64 eA = 2 * ((i64)(r - 1) * nx + (c - 1)) + 1, eB = 2 * ((i64)(r - 1) * nx + c), eC = eB + 1;
+      const i64 eD = 2 * ((i64)r * nx + (c - 1)), eE = eD + 1, eF = 2 * ((i64)r * nx + c);
+      // node (r, c): A = T1(r-1, c-1), B = T0(r-1, c), C = T1(r-1, c), D = T0(r, c-1), E = T1(r, c-1), F = T0(r, c)
+      lattice_node_entries(local, lm, emask, lo[k][1], lo[k + 1][0], lo[k + 1][1], hi[k][0], hi[k][1], hi[k + 1][0], eA, eB,
+                           eC, eD, eE, eF, up, dn, lf, rt, r * W + c, W, nx, n, nd, is_bc, g, vals, lift, Bv, b);
+    }
+#pragma unroll
+    for (int j = 0; j < RW + 1; ++j) { lo[j][0] = hi[j][0]; lo[j][1] = hi[j][1]; }
   }
 }
 
@@ -962,6 +1032,16 @@ extern "C" int diffhe_lattice_assemble_rows(const double* local, int local_compa
   const long long n = (long long)(nx + 1) * (ny + 1), m = 2LL * nx * ny;
   if (n > 2147483647LL) return DIFFHE_E_BADARG;
   diffhe::account(8.0 * Bv * ((double)nd * n + (lift ? n : 0) + ((kappa && kappa_se) ? m : 0)));
+  const int strip_on = getenv("DIFFHE_ASM_STRIP") ? atoi(getenv("DIFFHE_ASM_STRIP")) : 1;
+  if (strip_on && kappa && kappa_se && Bv >= kWave && Bv % kWave == 0 && nx >= 128 && ny >= 64) {
+    // per-sample kappa fields on a strip-sized level: every kappa_e loaded once per wave and quad row
+    const int TR = getenv("DIFFHE_ASM_TR") ? atoi(getenv("DIFFHE_ASM_TR")) : 8;
+    const int ncb = (nx + 1 + 4 * kAsmCols - 1) / (4 * kAsmCols), nrc = (ny + 1 + TR - 1) / TR;
+    hipLaunchKernelGGL(lattice_assemble_strip_kernel, dim3(ncb * nrc, Bv / kWave), dim3(256), 0, (hipStream_t)stream, local,
+                       (i64)(local_compact ? 2 : m), (i64)(local_compact ? 1 : -1), kappa, (i64)kappa_se, (i64)kappa_sb,
+                       is_bc, g, vals, lift, nx, ny, nd, Bv, ncb, TR);
+    return diffhe::check_launch();
+  }
   hipLaunchKernelGGL(lattice_assemble_kernel, diffhe::node_grid((int)n, Bv), dim3(256), 0, (hipStream_t)stream, local,
                      (i64)(local_compact ? 2 : m), (i64)(local_compact ? 1 : -1), kappa, kappa_se, kappa_sb, is_bc, g, vals,
                      lift, nx, ny, nd, Bv);

@@ -693,8 +693,11 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # SHIFT, A_b = kappa_b K_1 + diag(c m) (coefficients stay scalar loads; no cached dense inverse then: it would
         # depend on c / kappa_b); per-sample matrices get it added to their diagonals
         didx = plan.dense_level() if (factored and mg.get("dense_coarse", 1) and reaction == 0.0) else None
+        n_levels = None if didx is None else didx + 1
+        # (cutting the hierarchy of per-sample matrices at 9^2 / 17^2 / 33^2 -- 11 to 30 fewer launches per cycle, the last
+        # level on its Chebyshev iteration -- was measured: 9 + 9 -> 10 + 10 iterations, 208.6 -> 224.0 ... 226.9 ms; r4ab)
         vals, Bv, scale, lift, lift_scale = eng.lattice_assemble(kappa, mode, B, Bp, factor=closed_,
-                                                                 n_levels=None if didx is None else didx + 1, em=kappa_em)
+                                                                 n_levels=n_levels, em=kappa_em)
         shift = None
         if reaction and factored:
             shift = eng.reaction_shifts(reaction, len(vals))

@@ -908,3 +908,33 @@ def test_compact_element_matrices_of_congruent_lattices_give_bitwise_the_same_op
         out.append(dk)
     torch.cuda.synchronize()
     assert torch.equal(out[0], out[1]) and bool(torch.isfinite(out[0]).all())
+
+
+@pytest.mark.parametrize("nx,ny,Bv,bc", [(128, 64, 64, 0.4), (203, 77, 128, 0.25), (144, 81, 64, None)])
+def test_strip_form_of_the_per_sample_assembly_is_bitwise_the_node_per_wave_kernel(nx, ny, Bv, bc, monkeypatch):
+    """Per-sample kappa fields on a big level are assembled by a strip pass (a wave marches down RW node columns with the
+    kappa of two quad rows in registers: every kappa_e loaded once per wave and quad row instead of once per incident
+    node).  Same per-node arithmetic: bitwise the matrix and the lift of the node-per-wave kernel, for ragged widths and
+    heights (partial last strip, partial last row chunk), with the (9, m) and the compact tables, with and without
+    Dirichlet nodes."""
+    from diffhe import _hip
+    from diffhe.plan import _stream
+    mesh = FEMesh.rectangle(nx, ny, bc_value=bc) if bc is not None else _partly_neumann(nx, ny)
+    plan = get_plan(mesh, torch.device(DEV))
+    lev = plan.levels[0]
+    L, st = _hip.lib(), _stream(plan.device)
+    kap = torch.exp(0.5 * torch.randn(lev.m, Bv, dtype=T64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)))
+    tabs = [(lev.k0ref(), 0)] + ([(lev.compact("k0ref"), 1)] if lev.compact("k0ref") is not None else [])
+    for tab, flag in tabs:
+        res = []
+        for strip in ("0", "1"):
+            monkeypatch.setenv("DIFFHE_ASM_STRIP", strip)
+            v = torch.full((lev.nd, lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            lf = torch.full((lev.n, Bv), float("nan"), dtype=T64, device=DEV)
+            _hip.check(L.diffhe_lattice_assemble_rows(_hip.ptr(tab), flag, _hip.ptr(kap), Bv, 1, _hip.ptr(lev.is_bc),
+                                                      _hip.ptr(plan.g), _hip.ptr(v), _hip.ptr(lf), lev.nx, lev.ny, lev.nd, Bv,
+                                                      st), "assemble")
+            torch.cuda.synchronize()
+            res.append((v, lf))
+        assert bool(torch.isfinite(res[0][0]).all()) and bool(torch.isfinite(res[0][1]).all())
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (nx, ny, flag)
