@@ -323,9 +323,134 @@ __global__ __launch_bounds__(256) void apply_dirichlet_kernel(const int* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+// Row i of an ELL matrix against x for this lane's sample: acc -/+= a_k x[col_k], k = 0 .. W-1 in that order (the order
+// and the operations of the plain loop: bitwise the same sums).  The loads of NU entries are issued before the first
+// product (the plain loop waited for col_k, then for x[col_k], entry by entry: two exposed latencies per entry, 0.2 of
+// the HBM rate at 512^2 x 64); entries beyond W repeat entry 0 with the value 0.  With batches of >= 64 a wave works on
+// ONE node (FOR_EACH_NODE below) and takes ell_row_uniform instead.
+// ---------------------------------------------------------------------------------------
+template <bool SUB, int NU, typename TV, typename TM>
+__device__ __forceinline__ double ell_row_chunks(double acc, const TM* __restrict__ vals, const int* __restrict__ cols,
+                                                 const TV* __restrict__ x, int i, int n, int W, int Bp, int Bv, int b) {
+  const int vb = Bv == 1 ? 0 : b;
+  for (int k0 = 0; k0 < W; k0 += NU) {
+    int c[NU];
+    double a[NU];
+    TV xv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const bool in = k0 + u < W;
+      const i64 ent = (i64)(in ? k0 + u : 0) * n + i;
+      c[u] = cols[ent];
+      a[u] = in ? (double)vals[ent * Bv + vb] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) xv[u] = x[(i64)c[u] * Bp + b];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (SUB) acc -= a[u] * (double)xv[u];
+      else acc += a[u] * (double)xv[u];
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// The wave-uniform form (a wave = one node, all 64 lanes active): ONE vector load brings the node's column indices
+// (lane k: entry k; scalar loads came out one after the other, each waited for) and, for a batch-shared matrix
+// (SHARED), ONE its values; v_readlane hands them out as scalars BEFORE the gathers are issued, so the NU gathers of a
+// chunk are in flight together, each through a scalar row base + the lane's offset.  FULL: W == NU, one chunk, no
+// padding (P1 triangulations of lattice connectivity: 7 entries per row).  Same entries, same order, same operations.
+template <bool SUB, bool SHARED, int NU, bool FULL, typename TV, typename TM>
+__device__ __forceinline__ double ell_row_uniform(double acc, const TM* __restrict__ vals, const int* __restrict__ cols,
+                                                  const TV* __restrict__ x, int i, int n, int W, int Bp, int b) {
+  const int lane = threadIdx.x & 63;
+  for (int k0 = 0; k0 < W; k0 += kWave) {
+    const int nk = FULL ? NU : (W - k0 < kWave ? W - k0 : kWave);
+    const i64 entl = (i64)(k0 + (lane < nk ? lane : 0)) * n + i;
+    const int cv = cols[entl];
+    double av = 0.0;
+    if (SHARED) av = (double)vals[entl];
+    for (int u0 = 0; u0 < nk; u0 += NU) {
+      int c[NU];
+      double a[NU];
+      TV xv[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const bool in = FULL || u0 + u < nk;
+        const int k = in ? u0 + u : 0;
+        c[u] = __builtin_amdgcn_readlane(cv, k);
+        if (SHARED) a[u] = in ? readlane_f64(av, k) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const TV* __restrict__ xr = x + (i64)c[u] * Bp;   // scalar row base
+        xv[u] = xr[b];
+      }
+      if (!SHARED) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const bool in = FULL || u0 + u < nk;
+          const TM* __restrict__ vr = vals + ((i64)(k0 + (in ? u0 + u : 0)) * n + i) * Bp;
+          a[u] = in ? (double)vr[b] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (SUB) acc -= a[u] * (double)xv[u];
+        else acc += a[u] * (double)xv[u];
+      }
+    }
+  }
+  return acc;
+}
+template <bool SUB, bool UNI, bool SHARED, typename TV, typename TM>
+__device__ __forceinline__ double ell_row(double acc, const TM* __restrict__ vals, const int* __restrict__ cols,
+                                          const TV* __restrict__ x, int i, int n, int W, int Bp, int Bv, int b) {
+  if (UNI)
+    return W == 7 ? ell_row_uniform<SUB, SHARED, 7, true>(acc, vals, cols, x, i, n, W, Bp, b)
+                  : ell_row_uniform<SUB, SHARED, 8, false>(acc, vals, cols, x, i, n, W, Bp, b);
+  return ell_row_chunks<SUB, 8>(acc, vals, cols, x, i, n, W, Bp, Bv, b);
+}
+__device__ int g_xcd_ranges = 1;   // DIFFHE_ELL_XCD=0 (read once per process, sync_xcd_switch): the plain grid-stride walk
+__device__ __forceinline__ bool xcd_ranges() { return g_xcd_ranges != 0; }
+// for (i over this lane's nodes) BODY -- with batches of >= 64 through wave-uniform indices (see ell_row_uniform), and
+// with the nodes dealt to the XCDs in CONTIGUOUS ranges: workgroups go round-robin to the 8 XCDs (block b -> XCD b % 8),
+// each with its own L2, and a row's neighbours sit close to it in any sensible numbering.  With the plain grid-stride
+// walk every XCD saw every 8th group of 4 nodes, so each L2 fetched nearly ALL of x (the gathers of the fine-level Jacobi
+// sweep at 512^2 x 64 moved ~8x the vector through the fabric); now the blocks of one XCD sweep one eighth of the nodes
+// together and the gathers hit their own L2.  Which nodes a block sums changes, not the fixed order: still reproducible.
+#define FOR_EACH_NODE(nm_, n_, Bp_, Bv_, ...)                                                     \
+  do {                                                                                            \
+    if ((Bp_) >= kWave) {                                                                         \
+      constexpr bool kUni = true;                                                                 \
+      const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                 \
+      int first_ = (int)blockIdx.x * 4 + wave_u, hi_ = (n_), step_ = (int)gridDim.x * 4;          \
+      if ((gridDim.x & 7) == 0 && xcd_ranges()) {                                                 \
+        const int chunk_ = ((n_) + 7) >> 3, lo_ = ((int)blockIdx.x & 7) * chunk_;                 \
+        hi_ = lo_ + chunk_ < (n_) ? lo_ + chunk_ : (n_);                                          \
+        first_ = lo_ + ((int)blockIdx.x >> 3) * 4 + wave_u;                                       \
+        step_ = ((int)gridDim.x >> 3) * 4;                                                        \
+      }                                                                                           \
+      if ((Bv_) == 1) {                                                                           \
+        constexpr bool kShared = true;                                                            \
+        for (int i = first_; i < hi_; i += step_) __VA_ARGS__                                     \
+      } else {                                                                                    \
+        constexpr bool kShared = false;                                                           \
+        for (int i = first_; i < hi_; i += step_) __VA_ARGS__                                     \
+      }                                                                                           \
+    } else {                                                                                      \
+      constexpr bool kUni = false;                                                                \
+      constexpr bool kShared = false;                                                             \
+      for (int i = (nm_).node0; i < (n_); i += (nm_).stride) __VA_ARGS__                          \
+    }                                                                                             \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
 // y = (is_bc ? 0 : M x - sub), M batch-shared ELL.  Load vector and df = M^T lambda.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restrict__ vals,
+__global__ __launch_bounds__(256, 8) void spmv_shared_kernel(const double* __restrict__ vals,
                                                            const int* __restrict__ cols, const double* __restrict__ x,
                                                            const double* __restrict__ sub, int sub_B,
                                                            const double* __restrict__ sub_scale,
@@ -333,16 +458,12 @@ __global__ __launch_bounds__(256) void spmv_shared_kernel(const double* __restri
                                                            double* __restrict__ y, int n, int W, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
-  for (int i = nm.node0; i < n; i += nm.stride) {
-    double acc = 0.0;
-    for (int k = 0; k < W; ++k) {
-      const i64 ent = (i64)k * n + i;
-      acc += vals[ent] * x[(i64)cols[ent] * Bp + nm.b];
-    }
+  FOR_EACH_NODE(nm, n, Bp, 1, {
+    double acc = ell_row<false, kUni, kShared>(0.0, vals, cols, x, i, n, W, Bp, 1, nm.b);
     if (sub) acc -= (sub_scale ? sub_scale[nm.b] : 1.0) * sub[(i64)i * sub_B + (sub_B == 1 ? 0 : nm.b)];
     if (is_bc && is_bc[i]) acc = 0.0;
     y[(i64)i * Bp + nm.b] = acc;
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -387,25 +508,20 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const double* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void cg_spmv_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
+__global__ __launch_bounds__(256, 8) void cg_spmv_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
                                                        const double* __restrict__ p, double* __restrict__ Ap,
                                                        double* __restrict__ part_pAp, int n, int W, int Bp, int Bv) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
-  const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   if (ok)
-    for (int i = nm.node0; i < n; i += nm.stride) {
-      double acc = 0.0;
-      for (int k = 0; k < W; ++k) {
-        const i64 ent = (i64)k * n + i;
-        acc += vals[ent * Bv + vb] * p[(i64)cols[ent] * Bp + nm.b];
-      }
+    FOR_EACH_NODE(nm, n, Bp, Bv, {
+      const double acc = ell_row<false, kUni, kShared>(0.0, vals, cols, p, i, n, W, Bp, Bv, nm.b);
       const i64 o = (i64)i * Bp + nm.b;
       Ap[o] = acc;
       s += acc * p[o];
-    }
+    });
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double t = block_sum_per_sample(s, Bp, lds);
   if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part_pAp[(i64)blockIdx.x * Bp + nm.b] = t;
@@ -455,23 +571,18 @@ __global__ __launch_bounds__(256) void cg_update_p_kernel(const TZ* __restrict__
 }
 
 // true residual |b - A x|^2 partials
-__global__ __launch_bounds__(256) void residual_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
+__global__ __launch_bounds__(256, 8) void residual_kernel(const double* __restrict__ vals, const int* __restrict__ cols,
                                                         const double* __restrict__ bvec, const double* __restrict__ x,
                                                         double* __restrict__ part, int n, int W, int Bp, int Bv) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const bool ok = nm.b < Bp;
-  const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   if (ok)
-    for (int i = nm.node0; i < n; i += nm.stride) {
-      double acc = bvec[(i64)i * Bp + nm.b];
-      for (int k = 0; k < W; ++k) {
-        const i64 ent = (i64)k * n + i;
-        acc -= vals[ent * Bv + vb] * x[(i64)cols[ent] * Bp + nm.b];
-      }
+    FOR_EACH_NODE(nm, n, Bp, Bv, {
+      const double acc = ell_row<true, kUni, kShared>(bvec[(i64)i * Bp + nm.b], vals, cols, x, i, n, W, Bp, Bv, nm.b);
       s += acc * acc;
-    }
+    });
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double t = block_sum_per_sample(s, Bp, lds);
   if (wave == 0 && lane < (Bp < kWave ? Bp : kWave) && ok) part[(i64)blockIdx.x * Bp + nm.b] = t;
@@ -499,6 +610,33 @@ __device__ inline double sum_partials(const double* __restrict__ part, int nblk,
   const double t = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
   __syncthreads();
   return t;
+}
+
+// First stage of a long partial list (2048 rows on big meshes: ONE block of cg_scalar_kernel summing them took 68 us per
+// phase at 512^2 x 64, three phases per iteration): block (x, y, z) sums the rows y, y + S, ... of list z for the samples
+// of chunk x into row y of that list's slice table (S = kEllSlices rows); cg_scalar_kernel then sums S rows.  Fixed
+// assignment and order of additions: bitwise reproducible (the lattice solver's pcg_slice_kernel, for two lists at once).
+constexpr int kEllSlices = 16;
+__global__ __launch_bounds__(256) void cg_slice_kernel(const double* __restrict__ partA, const double* __restrict__ partB,
+                                                        int nblk, int Bp, double* __restrict__ slice) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWave + lane;
+  const int S = gridDim.y, y = blockIdx.y;
+  const double* __restrict__ part = blockIdx.z ? partB : partA;
+  double s0 = 0.0, s1 = 0.0;
+  if (b < Bp) {
+    int k = y + S * wave;
+    for (; k + 4 * S < nblk; k += 8 * S) {
+      s0 += part[(i64)k * Bp + b];
+      s1 += part[(i64)(k + 4 * S) * Bp + b];
+    }
+    if (k < nblk) s0 += part[(i64)k * Bp + b];
+  }
+  lds[wave * kWave + lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && b < Bp)
+    slice[((i64)blockIdx.z * S + y) * Bp + b] = (lds[lane] + lds[kWave + lane]) + (lds[2 * kWave + lane] + lds[3 * kWave + lane]);
 }
 
 enum { PH_INIT = 0, PH_ALPHA = 1, PH_BETA = 2, PH_RELRES = 3, PH_XX = 4, PH_SCALE = 5 };
@@ -711,7 +849,7 @@ __global__ __launch_bounds__(256) void ell_galerkin_kernel(const double* __restr
 // TV = storage type of the cycle's vectors, TM = storage type of the matrix values (fp32 copies inside a
 // single-precision preconditioner); arithmetic is fp64 in registers.
 template <typename TV, typename TM>
-__global__ __launch_bounds__(256) void ell_jacobi_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
+__global__ __launch_bounds__(256, 8) void ell_jacobi_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
                                                           const TV* __restrict__ bvec, const TV* __restrict__ xin,
                                                           TV* __restrict__ xout, double omega,
                                                           double* __restrict__ part, int n, int W, int Bp, int Bv) {
@@ -721,24 +859,21 @@ __global__ __launch_bounds__(256) void ell_jacobi_kernel(const TM* __restrict__ 
   const int vb = Bv == 1 ? 0 : nm.b;
   double s = 0.0;
   if (ok)
-    for (int i = nm.node0; i < n; i += nm.stride) {
+    FOR_EACH_NODE(nm, n, Bp, Bv, {
       const i64 o = (i64)i * Bp + nm.b;
       const double d = (double)vals[(i64)i * Bv + vb];
       const double bi = (double)bvec[o];
       double xo;
       if (xin) {
-        double acc = bi;
-        for (int k = 0; k < W; ++k) {
-          const i64 ent = (i64)k * n + i;
-          acc -= (double)vals[ent * Bv + vb] * (double)xin[(i64)cols[ent] * Bp + nm.b];
-        }
-        xo = (double)xin[o] + omega * acc / d;
+        const double xs = (double)xin[o];    // issued with the row's first loads, not behind its last product
+        const double acc = ell_row<true, kUni, kShared>(bi, vals, cols, xin, i, n, W, Bp, Bv, nm.b);
+        xo = xs + omega * acc / d;
       } else {
         xo = omega * bi / d;
       }
       xout[o] = (TV)xo;
       s += bi * xo;
-    }
+    });
   if (part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double t = block_sum_per_sample(s, Bp, lds);
@@ -747,20 +882,14 @@ __global__ __launch_bounds__(256) void ell_jacobi_kernel(const TM* __restrict__ 
 }
 
 template <typename TV, typename TM>
-__global__ __launch_bounds__(256) void ell_residual_out_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
+__global__ __launch_bounds__(256, 8) void ell_residual_out_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
                                                                 const TV* __restrict__ bvec, const TV* __restrict__ x,
                                                                 TV* __restrict__ r, int n, int W, int Bp, int Bv) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
-  const int vb = Bv == 1 ? 0 : nm.b;
-  for (int i = nm.node0; i < n; i += nm.stride) {
-    double acc = (double)bvec[(i64)i * Bp + nm.b];
-    for (int k = 0; k < W; ++k) {
-      const i64 ent = (i64)k * n + i;
-      acc -= (double)vals[ent * Bv + vb] * (double)x[(i64)cols[ent] * Bp + nm.b];
-    }
-    r[(i64)i * Bp + nm.b] = (TV)acc;
-  }
+  FOR_EACH_NODE(nm, n, Bp, Bv, {
+    r[(i64)i * Bp + nm.b] = (TV)ell_row<true, kUni, kShared>((double)bvec[(i64)i * Bp + nm.b], vals, cols, x, i, n, W, Bp, Bv, nm.b);
+  });
 }
 
 // rc = P^T r: rc[I] = sum over the members c of coarse node I (fixed order) of w_c r[member_c]; w == NULL: 1
@@ -995,6 +1124,21 @@ inline int cg_blocks(int n, int Bp) { return (int)node_grid(n, Bp).x; }
 
 }  // namespace
 
+// DIFFHE_ELL_XCD=0 switches the XCD-contiguous node ranges off (A/B); copied to the device once per process
+static int sync_xcd_switch(hipStream_t st) {
+  static int done = 0;
+  if (done) return DIFFHE_OK;
+  const int on = getenv("DIFFHE_ELL_XCD") ? atoi(getenv("DIFFHE_ELL_XCD")) : 1;
+  if (!on) {
+    const int rc = diffhe::check(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xcd_ranges), &on, sizeof(int), 0, hipMemcpyHostToDevice, st));
+    if (rc) return rc;
+    const int rc2 = diffhe::check(hipStreamSynchronize(st));
+    if (rc2) return rc2;
+  }
+  done = 1;
+  return DIFFHE_OK;
+}
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -1097,9 +1241,25 @@ extern "C" int diffhe_ell_spmv_shared(const double* vals, const int* cols, const
   return diffhe::check_launch();
 }
 
+// per-sample scalar phase of the CG loops below: long partial lists go through cg_slice_kernel first
+#define ELL_SCALAR(phase_, pa_, pb_)                                                                                      \
+  do {                                                                                                                    \
+    const double* pa__ = (pa_);                                                                                           \
+    const double* pb__ = (pb_);                                                                                           \
+    if (two_stage && nblk >= 256) {                                                                                       \
+      hipLaunchKernelGGL(cg_slice_kernel, dim3(sgrid.x, kEllSlices, pb__ ? 2 : 1), dim3(256), 0, st, pa__, pb__, nblk, Bp,  \
+                         slices);                                                                                         \
+      hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)(phase_), (const double*)slices,                 \
+                         pb__ ? (const double*)(slices + (long long)kEllSlices * Bp) : (const double*)nullptr,            \
+                         kEllSlices, Bp, tol, S, relres);                                                                 \
+    } else {                                                                                                              \
+      hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)(phase_), pa__, pb__, nblk, Bp, tol, S, relres); \
+    }                                                                                                                     \
+  } while (0)
+
 extern "C" long long diffhe_cg_workspace_doubles(int n, int Bp) {
   const long long nblk = cg_blocks(n, Bp);
-  return 4LL * n * Bp + 3LL * nblk * Bp + 16LL * Bp + 64;
+  return 4LL * n * Bp + 3LL * nblk * Bp + (16LL + 2 * kEllSlices) * Bp + 64;
 }
 
 extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const double* b, double* x, int n, int W,
@@ -1111,6 +1271,7 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
   if (Bv != 1 && Bv != Bp) return DIFFHE_E_BADARG;
   if (check_every < 1) check_every = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (int rcx = sync_xcd_switch(st)) return rcx;
   const dim3 grid = diffhe::node_grid(n, Bp);
   const int nblk = grid.x;
   const long long NB = (long long)n * Bp;
@@ -1133,20 +1294,21 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
   S.maxdiag = nullptr;
   S.Bv = Bv;
   const dim3 sgrid((Bp + 63) / 64);
+  double* const slices = sc + 16LL * Bp;   // 2 x kEllSlices rows
+  static const int two_stage = getenv("DIFFHE_ELL_SCALAR2") ? atoi(getenv("DIFFHE_ELL_SCALAR2")) : 1;
 
   hipLaunchKernelGGL(cg_init_kernel, grid, dim3(256), 0, st, vals, b, x, r, z, p, partA, partB, n, Bp, Bv);
-  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, partA, partB, nblk, Bp, tol, S, relres);
+  ELL_SCALAR(PH_INIT, (const double*)partA, (const double*)partB);
   int rc = diffhe::check_launch();
   if (rc) return rc;
 
   int it = 0, n_active = -1;
   while (it < max_iter) {
     hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, vals, cols, p, Ap, partA, n, W, Bp, Bv);
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, partA, (const double*)nullptr, nblk,
-                       Bp, tol, S, relres);
+    ELL_SCALAR(PH_ALPHA, (const double*)partA, (const double*)nullptr);
     hipLaunchKernelGGL(cg_update_kernel, grid, dim3(256), 0, st, vals, p, Ap, S.alpha, x, r, z, partB, partC, n, Bp,
                        Bv);
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, partB, partC, nblk, Bp, tol, S, relres);
+    ELL_SCALAR(PH_BETA, (const double*)partB, (const double*)partC);
     hipLaunchKernelGGL(cg_update_p_kernel<double>, grid, dim3(256), 0, st, (const double*)z, (const double*)S.beta, p, n, Bp);
     ++it;
     if (it % check_every == 0 || it == max_iter) {
@@ -1159,8 +1321,7 @@ extern "C" int diffhe_ell_cg_solve(const double* vals, const int* cols, const do
     }
   }
   hipLaunchKernelGGL(residual_kernel, grid, dim3(256), 0, st, vals, cols, b, x, partA, n, W, Bp, Bv);
-  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_RELRES, partA, (const double*)nullptr, nblk,
-                     Bp, tol, S, relres);
+  ELL_SCALAR(PH_RELRES, (const double*)partA, (const double*)nullptr);
   rc = diffhe::check_launch();
   if (rc) return rc;
   status_host[0] = it;
@@ -1193,7 +1354,7 @@ extern "C" long long diffhe_ell_amg_workspace_doubles(const diffhe_amg_level* le
   if (amg_fill(H, levels, n_levels, 1, Bp)) return -1;
   const long long nb = (long long)H.lev[0].n * Bp;
   const long long nblk = cg_blocks(H.lev[0].n, Bp);
-  return amg_carve(H, nullptr) + 3 * nb + 4 * nblk * Bp + 16LL * Bp + 64;
+  return amg_carve(H, nullptr) + 3 * nb + 4 * nblk * Bp + (16LL + 2 * kEllSlices) * Bp + 64;
 }
 
 extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_levels, int Bv, const double* b, double* x,
@@ -1207,6 +1368,7 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   H.n_coarse = n_coarse; H.gamma = gamma; H.scale = scale;
   H.w0 = 0.56; H.w1 = 1.39;  // Chebyshev weights for the interval [0.5, 2] of D^-1 A
   hipStream_t st = (hipStream_t)stream;
+  if (int rcx = sync_xcd_switch(st)) return rcx;
   const diffhe_amg_level& L0 = H.lev[0];
   const int n = L0.n, W = L0.W;
   const dim3 grid = diffhe::node_grid(n, Bp);
@@ -1232,6 +1394,8 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   S.maxdiag = sc + 10 * Bp;
   S.Bv = Bv;
   const dim3 sgrid((Bp + 63) / 64);
+  double* const slices = sc + 16LL * Bp;   // 2 x kEllSlices rows
+  static const int two_stage = getenv("DIFFHE_ELL_SCALAR2") ? atoi(getenv("DIFFHE_ELL_SCALAR2")) : 1;
   rc = diffhe::check(hipMemsetAsync((void*)S.maxdiag, 0, sizeof(double) * Bv, st));
   if (rc) return rc;
   if (S.xx) {
@@ -1256,29 +1420,24 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   };
   hipLaunchKernelGGL(amg_init_kernel, grid, dim3(256), 0, st, b, x, r, r32, p, partC, n, Bp);
   if (f32) {  // fp32 copy of rs * b, rs ~ 1 / |b| a power of two: keeps the cycle inside the fp32 range
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_SCALE, (const double*)partC,
-                       (const double*)nullptr, nblk, Bp, tol, S, relres);
+    ELL_SCALAR(PH_SCALE, (const double*)partC, (const double*)nullptr);
     hipLaunchKernelGGL(amg_cvt_kernel, grid, dim3(256), 0, st, (const double*)r, (const double*)S.rs, r32, n, Bp);
   }
   precondition();
-  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_INIT, (const double*)partB, (const double*)partC,
-                     nblk, Bp, tol, S, relres);
+  ELL_SCALAR(PH_INIT, (const double*)partB, (const double*)partC);
   update_p();  // beta = 0: p = z
   rc = diffhe::check_launch();
   if (rc) return rc;
   int it = 0, n_active = -1;
   while (it < max_iter) {
     hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, (const double*)p, Ap, partA, n, W, Bp, Bv);
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_ALPHA, (const double*)partA,
-                       (const double*)nullptr, nblk, Bp, tol, S, relres);
+    ELL_SCALAR(PH_ALPHA, (const double*)partA, (const double*)nullptr);
     hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
                        (const double*)S.alpha, x, r, r32, (const double*)S.rs, partC, S.xx ? partD : (double*)nullptr, n, Bp);
     if (S.xx)
-      hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_XX, (const double*)partD,
-                         (const double*)nullptr, nblk, Bp, tol, S, relres);
+      ELL_SCALAR(PH_XX, (const double*)partD, (const double*)nullptr);
     precondition();
-    hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_BETA, (const double*)partB, (const double*)partC,
-                       nblk, Bp, tol, S, relres);
+    ELL_SCALAR(PH_BETA, (const double*)partB, (const double*)partC);
     update_p();
     ++it;
     rc = diffhe::check(hipMemcpyAsync(&status_host[2], S.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1289,8 +1448,7 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
     if (n_active == 0) break;
   }
   hipLaunchKernelGGL(residual_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, b, (const double*)x, partA, n, W, Bp, Bv);
-  hipLaunchKernelGGL(cg_scalar_kernel, sgrid, dim3(256), 0, st, (int)PH_RELRES, (const double*)partA,
-                     (const double*)nullptr, nblk, Bp, tol, S, relres);
+  ELL_SCALAR(PH_RELRES, (const double*)partA, (const double*)nullptr);
   rc = diffhe::check_launch();
   if (rc) return rc;
   status_host[0] = it;
