@@ -421,18 +421,25 @@ __device__ __forceinline__ bool xcd_ranges() { return g_xcd_ranges != 0; }
 // walk every XCD saw every 8th group of 4 nodes, so each L2 fetched nearly ALL of x (the gathers of the fine-level Jacobi
 // sweep at 512^2 x 64 moved ~8x the vector through the fabric); now the blocks of one XCD sweep one eighth of the nodes
 // together and the gathers hit their own L2.  Which nodes a block sums changes, not the fixed order: still reproducible.
+// nodes first, first + step, ... < hi of this wave in the wave-per-node walk (XCD-contiguous ranges when the grid allows)
+__device__ __forceinline__ void wave_node_range(int n, int& first, int& hi, int& step) {
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  first = (int)blockIdx.x * 4 + wave_u;
+  hi = n;
+  step = (int)gridDim.x * 4;
+  if ((gridDim.x & 7) == 0 && xcd_ranges()) {
+    const int chunk = (n + 7) >> 3, lo = ((int)blockIdx.x & 7) * chunk;
+    hi = lo + chunk < n ? lo + chunk : n;
+    first = lo + ((int)blockIdx.x >> 3) * 4 + wave_u;
+    step = ((int)gridDim.x >> 3) * 4;
+  }
+}
 #define FOR_EACH_NODE(nm_, n_, Bp_, Bv_, ...)                                                     \
   do {                                                                                            \
     if ((Bp_) >= kWave) {                                                                         \
       constexpr bool kUni = true;                                                                 \
-      const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                 \
-      int first_ = (int)blockIdx.x * 4 + wave_u, hi_ = (n_), step_ = (int)gridDim.x * 4;          \
-      if ((gridDim.x & 7) == 0 && xcd_ranges()) {                                                 \
-        const int chunk_ = ((n_) + 7) >> 3, lo_ = ((int)blockIdx.x & 7) * chunk_;                 \
-        hi_ = lo_ + chunk_ < (n_) ? lo_ + chunk_ : (n_);                                          \
-        first_ = lo_ + ((int)blockIdx.x >> 3) * 4 + wave_u;                                       \
-        step_ = ((int)gridDim.x >> 3) * 4;                                                        \
-      }                                                                                           \
+      int first_, hi_, step_;                                                                     \
+      wave_node_range((n_), first_, hi_, step_);                                                  \
       if ((Bv_) == 1) {                                                                           \
         constexpr bool kShared = true;                                                            \
         for (int i = first_; i < hi_; i += step_) __VA_ARGS__                                     \
@@ -517,10 +524,11 @@ __global__ __launch_bounds__(256, 8) void cg_spmv_kernel(const double* __restric
   double s = 0.0;
   if (ok)
     FOR_EACH_NODE(nm, n, Bp, Bv, {
-      const double acc = ell_row<false, kUni, kShared>(0.0, vals, cols, p, i, n, W, Bp, Bv, nm.b);
       const i64 o = (i64)i * Bp + nm.b;
+      const double ps = p[o];    // issued with the row's first loads
+      const double acc = ell_row<false, kUni, kShared>(0.0, vals, cols, p, i, n, W, Bp, Bv, nm.b);
       Ap[o] = acc;
-      s += acc * p[o];
+      s += acc * ps;
     });
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double t = block_sum_per_sample(s, Bp, lds);
@@ -901,6 +909,42 @@ __global__ __launch_bounds__(256) void agg_restrict_kernel(const TV* __restrict_
                                                             int nc, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
+  if (Bp >= kWave) {
+    // a wave = one coarse node: 64 member indices (and weights) per vector load, handed out by v_readlane, the gathers
+    // of 8 members in flight together -- the plain loop below waited twice per member (33-40 us on levels of a few
+    // hundred coarse nodes, whose rows of P^T have 30-40 entries).  Same members, same order, same operations.
+    const int lane = threadIdx.x & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int I = (int)blockIdx.x * 4 + wave_u; I < nc; I += (int)gridDim.x * 4) {
+      const int beg = agg_ptr[I], end = agg_ptr[I + 1];
+      double s = 0.0;
+      for (int c0 = beg; c0 < end; c0 += kWave) {
+        const int nk = end - c0 < kWave ? end - c0 : kWave;
+        const int cl = c0 + (lane < nk ? lane : 0);
+        const int mv = members[cl];
+        const double wv = w ? w[cl] : 1.0;
+        for (int u0 = 0; u0 < nk; u0 += 8) {
+          double ww[8];
+          TV rv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = u0 + u < nk ? u0 + u : 0;
+            const TV* __restrict__ rr = r + (i64)__builtin_amdgcn_readlane(mv, k) * Bp;
+            rv[u] = rr[nm.b];
+            ww[u] = w ? readlane_f64(wv, k) : 1.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (u0 + u < nk) {
+              if (w) s = fma(ww[u], (double)rv[u], s);
+              else s += (double)rv[u];
+            }
+        }
+      }
+      rc[(i64)I * Bp + nm.b] = (TV)s;
+    }
+    return;
+  }
   for (int I = nm.node0; I < nc; I += nm.stride) {
     double s = 0.0;
     if (w)
@@ -918,6 +962,43 @@ __global__ __launch_bounds__(256) void sa_prolong_add_kernel(const TV* __restric
                                                               TV* __restrict__ x, double scale, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   if (nm.b >= Bp) return;
+  if (Bp >= kWave && pw <= 8) {
+    // a wave = one fine node: its row of P in one vector load (lane k: entry k), entries handed out by v_readlane, the
+    // gathers of e in flight together with the node's own x.  Same entries, same order, same operations.
+    const int lane = threadIdx.x & 63;
+    int first, hi, step;
+    wave_node_range(n, first, hi, step);
+    for (int i = first; i < hi; i += step) {
+      const i64 entl = (i64)(lane < pw ? lane : 0) * n + i;
+      const int cv = p_cols[entl];
+      const double pv = p_vals[entl];
+      const i64 o = (i64)i * Bp + nm.b;
+      const TV xs = x[o];
+      TV ev[8];
+      double pp[8];
+      int II[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        II[u] = u < pw ? __builtin_amdgcn_readlane(cv, u) : -1;
+        pp[u] = readlane_f64(pv, u);
+        ev[u] = (TV)0;
+        if (II[u] >= 0) {    // wave-uniform: no load for an absent entry
+          const TV* __restrict__ er = e + (i64)II[u] * Bp;
+          ev[u] = er[nm.b];
+        }
+      }
+      double s = 0.0;
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (II[u] >= 0) {
+          s = fma(pp[u], (double)ev[u], s);
+          any = true;
+        }
+      if (any) x[o] = (TV)((double)xs + scale * s);
+    }
+    return;
+  }
   for (int i = nm.node0; i < n; i += nm.stride) {
     double s = 0.0;
     bool any = false;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# kernel times of one steady general-path solve (tools/amg_bench.py under rocprofv3):  bash tools/amg_profile.sh outdir [N B gamma]
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${1:-amgprof}; shift
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $out -o amg -- python3 $R/tools/amg_bench.py ${@:-512 64 1} > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+python3 - $out <<'PY'
+import csv, glob, re, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"])) for r in csv.DictReader(open(f))))
+gaps = sorted(((rows[i + 1][0] - rows[i][1], i) for i in range(len(rows) - 1)), reverse=True)
+sel = rows[gaps[0][1] + 1:]                      # the second (steady) solve: after the longest idle gap
+agg = {}
+for s, e, n, g in sel:
+    k = (re.sub(r"\(anonymous namespace\)::|void ", "", n)[:48], g)
+    a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e6
+print("steady solve: %d launches, span %.2f ms, busy %.2f ms" % (len(sel), (sel[-1][1] - sel[0][0]) / 1e6, sum(a[1] for a in agg.values())))
+for k, a in sorted(agg.items(), key=lambda x: -x[1][1])[:18]:
+    print("%8.3f ms %5d  avg %7.1f us  grid %8d %s" % (a[1], a[0], a[1] / a[0] * 1e3, k[1], k[0]))
+PY
