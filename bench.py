@@ -439,7 +439,7 @@ def main():
         torch.cuda.empty_cache()
     if single:
         for name, fn in (("config2_1d_10000_b1024", variant_config2), ("config3_512_b256", variant_config3),
-                         ("config5_512_b64_adam", variant_config5)):
+                         ("config5_512_b64_adam", variant_config5), ("general_mesh_jittered_512_b64", variant_general_mesh)):
             if want(name):
                 variants[name] = fn(args, torch, L, _hip, ctypes, dev, timed)
                 torch.cuda.empty_cache()
@@ -735,6 +735,45 @@ def variant_config5(args, torch, L, _hip, ctypes, dev, timed):
             "ms_per_adam_step": round(1e3 * tv / STEPS, 3), "ms_all": [round(1e3 * x / STEPS, 3) for x in ts],
             "iterations": {"fwd_mean": state["its"][0] / STEPS, "adj_mean": state["its"][1] / STEPS},
             "loss_after_10_steps": state["loss"], "roofline": roof}
+
+
+def variant_general_mesh(args, torch, L, _hip, ctypes, dev, timed):
+    """The general (ELL / smoothed-aggregation PCG) path, which every mesh that is not a lattice takes: rectangle(512, 512)
+    with its interior nodes jittered by +-0.25 h (seed 0; the connectivity stays, the solver is told method="ell" and
+    sees an unstructured mesh), 64 samples, one scalar kappa per sample ~ U(0.5, 2), f = 1; forward + loss + backward."""
+    import numpy as np
+    from diffhe import FEMesh, DifferentiableFESolver
+    N, B = 512, 64
+    base = FEMesh.rectangle(N, N)
+    rng = np.random.default_rng(0)
+    nodes = base.nodes.numpy().copy()
+    h = 1.0 / N
+    inner = (nodes[:, 0] > 1e-9) & (nodes[:, 0] < 1 - 1e-9) & (nodes[:, 1] > 1e-9) & (nodes[:, 1] < 1 - 1e-9)
+    nodes[inner] += rng.uniform(-0.25 * h, 0.25 * h, (int(inner.sum()), 2))
+    mesh = FEMesh(nodes=torch.from_numpy(nodes), elements=base.elements, dirichlet_nodes=dict(base.dirichlet_nodes))
+    kappa = torch.from_numpy(rng.uniform(0.5, 2.0, B)).to(dev).requires_grad_(True)
+    f = torch.ones(B, mesh.n_nodes, dtype=torch.float64, device=dev)
+    solver = DifferentiableFESolver(mesh, kappa, device=dev, method="ell")
+
+    def fwd():
+        with torch.no_grad():
+            solver(f)
+
+    def step():
+        kappa.grad = None
+        u = solver(f)
+        (torch.linalg.vector_norm(u, dim=1).square().sum() / B).backward()
+
+    tf, _ = timed(fwd)
+    it_f = solver.last_info.iterations
+    tv, ts = timed(step)
+    info = solver.last_info
+    return {"what": "jittered 512 x 512 triangulation through method='ell' (smoothed-aggregation PCG, the path of every "
+                    "unstructured mesh), 64 samples, scalar kappa per sample, reference API layout (B, n)",
+            "value_per_gpu": round(B / tv, 1), "ms_per_step": round(1e3 * tv, 3), "ms_all": [round(1e3 * x, 2) for x in ts],
+            "forward_only_ms": round(1e3 * tf, 3), "forward_ms_per_iteration": round(1e3 * tf / max(it_f, 1), 4),
+            "iters_fwd": info.iterations, "iters_adj": info.adj_iterations, "path": info.path,
+            "factored": bool(info.factored), "max_relres": info.max_relres, "not_converged": info.not_converged}
 
 
 def dry_run(args, rank, world, dist, torch):
