@@ -2228,13 +2228,34 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
                                                           const double* __restrict__ alpha, double* __restrict__ x,
                                                           double* __restrict__ r, float* __restrict__ r32,
                                                           const double* __restrict__ rs, double* __restrict__ part,
-                                                          int n, int Bp) {
+                                                          int n, int Bp, int unroll = 0) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double a = alpha[nm.b];
   const double sc = (r32 && rs) ? rs[nm.b] : 1.0;
   double s = 0.0;
-  for (int i = nm.node0; i < n; i += nm.stride) {
+  int i = nm.node0;
+  // four nodes per trip (the loads of all four in flight together; one node per trip left a wave with two loads
+  // outstanding: 4.8 TB/s); same nodes, same order of the partial sum
+  if (unroll && !x)
+    for (; (i64)i + 3LL * nm.stride < n; i += 4 * nm.stride) {
+      double rv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const i64 o = (i64)(i + u * nm.stride) * Bp + nm.b;
+        rv[u] = __builtin_nontemporal_load(r + o);
+        av[u] = __builtin_nontemporal_load(Ap + o);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const i64 o = (i64)(i + u * nm.stride) * Bp + nm.b;
+        const double ri = rv[u] - a * av[u];
+        __builtin_nontemporal_store(ri, r + o);
+        if (r32) r32[o] = (float)(ri * sc);
+        s += ri * ri;
+      }
+    }
+  for (; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     if (x) x[o] += a * p[o];  // x == NULL: the iterate update is fused into the next operator apply
     const double ri = __builtin_nontemporal_load(r + o) - a * __builtin_nontemporal_load(Ap + o);
@@ -2245,6 +2266,9 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(const double* __restric
   STORE_PARTIAL(part, s);
 }
 
+// (Two samples per lane -- 16-byte loads and stores, a wave moving 1 KB per instruction -- were measured for this kernel
+// and for pcg_finish_kernel: 212.9 / 213.8 -> 214.6 / 214.2 ms per step of the per-element-field variant, headline step
+// unchanged, gpurun_out/r4an.  At 4.9 TB/s these passes run at the rate of the box's own device-to-device copy.)
 // y += x (TV) ; and the start of the CG from a full-multigrid iterate: x64 = (double) x0
 template <typename TV>
 __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, TV* __restrict__ y, int n, int Bp) {
@@ -2258,12 +2282,31 @@ __global__ __launch_bounds__(256) void mg_add_kernel(const TV* __restrict__ x, T
 template <typename TV>
 __global__ __launch_bounds__(256) void pcg_setx_kernel(const TV* __restrict__ x0, const double* __restrict__ rs,
                                                         double* __restrict__ x, double* __restrict__ part, int n,
-                                                        int Bp, int add = 0, const TV* __restrict__ e0 = nullptr) {
+                                                        int Bp, int add = 0, const TV* __restrict__ e0 = nullptr,
+                                                        int unroll = 0) {
   __shared__ double lds[4 * kWave];
   const NodeMap nm = node_map(Bp);
   const double inv = rs ? 1.0 / rs[nm.b] : 1.0;  // the start was computed from the scaled right-hand side
   double s = 0.0;
-  for (int i = nm.node0; i < n; i += nm.stride) {
+  int i = nm.node0;
+  if (unroll && !add)   // four nodes per trip (see pcg_update_kernel)
+    for (; (i64)i + 3LL * nm.stride < n; i += 4 * nm.stride) {
+      TV xv[4], ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const i64 o = (i64)(i + u * nm.stride) * Bp + nm.b;
+        xv[u] = x0[o];
+        ev[u] = e0 ? e0[o] : (TV)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const i64 o = (i64)(i + u * nm.stride) * Bp + nm.b;
+        const double v = ((double)xv[u] + (e0 ? (double)ev[u] : 0.0)) * inv + 0.0;
+        x[o] = v;
+        s += v * v;
+      }
+    }
+  for (; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     // add: x0 is a correction of the caller's iterate;  e0: the last cycle's correction of x0, not yet added (fmg_start)
     const double v = ((double)x0[o] + (e0 ? (double)e0[o] : 0.0)) * inv + (add ? x[o] : 0.0);
@@ -2298,7 +2341,15 @@ __global__ __launch_bounds__(256) void pcg_cvt_kernel(const double* __restrict__
                                                        float* __restrict__ r32, int n, int Bp) {
   const NodeMap nm = node_map(Bp);
   const double sc = rs ? rs[nm.b] : 1.0;
-  for (int i = nm.node0; i < n; i += nm.stride) {
+  int i = nm.node0;
+  for (; (i64)i + 3LL * nm.stride < n; i += 4 * nm.stride) {   // four nodes per trip: four loads in flight per wave
+    double rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rv[u] = r[(i64)(i + u * nm.stride) * Bp + nm.b];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r32[(i64)(i + u * nm.stride) * Bp + nm.b] = (float)(rv[u] * sc);
+  }
+  for (; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     r32[o] = (float)(r[o] * sc);
   }
@@ -2329,7 +2380,7 @@ template <typename TP>
 __global__ __launch_bounds__(256) void pcg_finish_kernel(const double* __restrict__ alpha, const TP* __restrict__ p,
                                                           long long slot_stride, int j0, int count, int n_slots,
                                                           const TP* __restrict__ z, const double* __restrict__ rs,
-                                                          double* __restrict__ x, int n, int Bp) {
+                                                          double* __restrict__ x, int n, int Bp, int unroll = 0) {
   // x += sum_{j = j0 .. j0 + count - 1} alpha_j p_j (+ z / rs): direction j lives in slot j % n_slots of `p`, its
   // step lengths in row j % n_slots of `alpha` (0 for samples that had stopped)
   const NodeMap nm = node_map(Bp);
@@ -2337,7 +2388,28 @@ __global__ __launch_bounds__(256) void pcg_finish_kernel(const double* __restric
   double a[kRingSlots];
 #pragma unroll
   for (int k = 0; k < kRingSlots; ++k) a[k] = k < count ? alpha[(long long)((j0 + k) % n_slots) * Bp + nm.b] : 0.0;
-  for (int i = nm.node0; i < n; i += nm.stride) {
+  int i = nm.node0;
+  if (unroll)   // two nodes per trip: twice the loads in flight per wave (same operations per node)
+    for (; (i64)i + nm.stride < n; i += 2 * nm.stride) {
+      const i64 o0 = (i64)i * Bp + nm.b, o1 = (i64)(i + nm.stride) * Bp + nm.b;
+      double v0 = x[o0], v1 = x[o1];
+      TP z0 = z ? z[o0] : (TP)0, z1 = z ? z[o1] : (TP)0;
+      TP p0[kRingSlots], p1[kRingSlots];
+#pragma unroll
+      for (int k = 0; k < kRingSlots; ++k)
+        if (k < count) {
+          const long long so = (long long)((j0 + k) % n_slots) * slot_stride;
+          p0[k] = p[so + o0];
+          p1[k] = p[so + o1];
+        }
+      if (z) { v0 += zi * (double)z0; v1 += zi * (double)z1; }
+#pragma unroll
+      for (int k = 0; k < kRingSlots; ++k)
+        if (k < count) { v0 += a[k] * (double)p0[k]; v1 += a[k] * (double)p1[k]; }
+      x[o0] = v0;
+      x[o1] = v1;
+    }
+  for (; i < n; i += nm.stride) {
     const i64 o = (i64)i * Bp + nm.b;
     double v = x[o];
     if (z) v += zi * (double)z[o];
@@ -3346,6 +3418,8 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
   const dim3 sgrid((Bp + 63) / 64);
   double* const slices = sc + 32LL * Bp;          // kScalarSlices rows: first stage of long partial lists
   static const int two_stage = getenv("DIFFHE_SCALAR2") ? atoi(getenv("DIFFHE_SCALAR2")) : 1;
+  // several nodes per trip in the grid-stride vector kernels (A/B: DIFFHE_VEC_UNROLL=0)
+  static const int vec_unroll = getenv("DIFFHE_VEC_UNROLL") ? atoi(getenv("DIFFHE_VEC_UNROLL")) : 1;
 #define SCALAR(phase, part, nb_)                                                                                           \
   do {                                                                                                                     \
     if (two_stage && (int)(nb_) >= 256) {                                                                                  \
@@ -3419,10 +3493,10 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
     const double bytes = 16.0 + (f32 ? 4.0 : 8.0) * (count + (with_z ? 1 : 0));
     if (f32)
       LAUNCH(bytes, pcg_finish_kernel<float>, n, (const double*)alpha_ring, (const float*)(const void*)p, slot_stride,
-             flushed, count, n_slots, with_z ? (const float*)z : (const float*)nullptr, (const double*)S.rs, x, n, Bp);
+             flushed, count, n_slots, with_z ? (const float*)z : (const float*)nullptr, (const double*)S.rs, x, n, Bp, vec_unroll);
     else
       LAUNCH(bytes, pcg_finish_kernel<double>, n, (const double*)alpha_ring, (const double*)p, slot_stride, flushed, count,
-             n_slots, with_z ? (const double*)z : (const double*)nullptr, (const double*)nullptr, x, n, Bp);
+             n_slots, with_z ? (const double*)z : (const double*)nullptr, (const double*)nullptr, x, n, Bp, vec_unroll);
     flushed = it;
   };
   auto precondition = [&](int first) {
@@ -3527,13 +3601,13 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
       const float* x0 = fmg_start<float>(H, (const float*)r32, st, &e0);
       if (!x0) return DIFFHE_E_LAUNCH;
       LAUNCH((warm ? 20.0 : 12.0) + (e0 ? 4.0 : 0.0), pcg_setx_kernel<float>, n, x0, (const double*)S.rs, x,
-             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0);
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0, vec_unroll);
     } else {
       const double* e0 = nullptr;
       const double* x0 = fmg_start<double>(H, warm ? (const double*)r : b, st, &e0);
       if (!x0) return DIFFHE_E_LAUNCH;
       LAUNCH((warm ? 24.0 : 16.0) + (e0 ? 8.0 : 0.0), pcg_setx_kernel<double>, n, x0, (const double*)nullptr, x,
-             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0);
+             use_floor ? partA : (double*)nullptr, n, Bp, warm ? 1 : 0, e0, vec_unroll);
     }
     if (use_floor) SCALAR(S_FLOOR, partA, nblk);
     residual_pass(true);
@@ -3565,7 +3639,7 @@ extern "C" int diffhe_lattice_pcg_solve(const diffhe_mg_level* levels, int n_lev
 #undef RUV
     } else {
       LAUNCH(24.0 + (r32 ? 4.0 : 0.0) + (fused ? 0.0 : 24.0), pcg_update_kernel, n, (const double*)p, (const double*)Ap, (const double*)S.alpha, fused ? (double*)nullptr : x,
-             r, r32, (const double*)S.rs, partA, n, Bp);
+             r, r32, (const double*)S.rs, partA, n, Bp, vec_unroll);
     }
     kp_end(KP_UPDATE, st);
     SCALAR(S_CONV, partA, rupd ? (rupd_mode == 4 ? g8.ncb * g8.nrc : g0.ncb * g0.nrc) : nblk);
