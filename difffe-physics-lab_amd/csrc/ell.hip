@@ -1120,12 +1120,38 @@ struct AmgHier {
 // x ~= A_l^{-1} rhs from a zero guess: V(2,2) weighted Jacobi, `gamma` coarse corrections per level
 // (gamma = 2: W-cycle -- affordable because aggregation coarsens by ~10x -- compensates the weak
 // piecewise-constant interpolation).  Returns the buffer holding the result.
+// Last level of a batch-shared hierarchy: x = A^-1 rhs as ONE dense product with the cached inverse (n <= 128; the 16
+// Jacobi sweeps it replaces were 16 launch-bound launches per cycle and only an approximate solve).  A block = 64
+// samples: rhs staged in LDS, each wave takes rows i = wave, wave + 16, ...; the row of the inverse is wave-uniform.
+template <typename TV>
+__global__ __launch_bounds__(1024) void amg_dense_solve_kernel(const double* __restrict__ inv, const TV* __restrict__ rhs,
+                                                                TV* __restrict__ x, int n, int Bp) {
+  extern __shared__ double sm[];   // (n, 64)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+  const int b = blockIdx.x * kWave + lane;
+  const bool ok = b < Bp;
+  for (int j = wave; j < n; j += nw) sm[j * kWave + lane] = ok ? (double)rhs[(i64)j * Bp + b] : 0.0;
+  __syncthreads();
+  for (int i = wave; i < n; i += nw) {
+    const double* __restrict__ row = inv + (i64)i * n;
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(row[j], sm[j * kWave + lane], acc);
+    if (ok) x[(i64)i * Bp + b] = (TV)acc;
+  }
+}
+
 template <typename TV>
 TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream_t st) {
   const diffhe_amg_level& L = H.lev[l];
   TV* a = (TV*)H.xa[l];
   TV* b2 = (TV*)H.xb[l];
   const bool last = (l == H.nl - 1);
+  if (last && l > 0 && L.dense_inv && H.Bv == 1 && L.n <= 128) {
+    hipLaunchKernelGGL(amg_dense_solve_kernel<TV>, dim3((H.Bp + kWave - 1) / kWave), dim3(1024),
+                       sizeof(double) * L.n * kWave, st, L.dense_inv, rhs, a, L.n, H.Bp);
+    return a;
+  }
   const int pre = last ? H.n_coarse : 2;
   // per-sample matrices inside the fp32 cycle read the fp32 copy of the values
   const bool m32 = sizeof(TV) == 4 && H.Bv != 1 && L.vals32 != nullptr;

@@ -28,7 +28,8 @@ _LV = C.POINTER(MgLevel)
 class AmgLevel(C.Structure):
     """struct diffhe_amg_level (include/diffhe_hip.h)."""
     _fields_ = [("n", _I), ("W", _I), ("vals", _P), ("cols", _P), ("agg", _P), ("agg_ptr", _P), ("agg_members", _P),
-                ("vals32", _P), ("agg_weights", _P), ("p_cols", _P), ("p_vals", _P), ("p_width", _I), ("reserved", _I)]
+                ("vals32", _P), ("agg_weights", _P), ("p_cols", _P), ("p_vals", _P), ("p_width", _I), ("reserved", _I),
+                ("dense_inv", _P)]
 
 
 _AV = C.POINTER(AmgLevel)

@@ -413,9 +413,11 @@ class _Engine:
         return x, int(st[0]), int(st[1]), relres
 
     # -- general path with the aggregation-multigrid preconditioner ---------------------------------
-    def amg_setup(self, vals, Bv, fp32=True, levels=None):
+    def amg_setup(self, vals, Bv, fp32=True, levels=None, dense_coarse=False):
         """Per-solve coarse operators (Galerkin sums of the fine values) + the level descriptor array.
-        fp32: per-sample matrices also get an fp32 copy of every level's values for the fp32 cycle."""
+        fp32: per-sample matrices also get an fp32 copy of every level's values for the fp32 cycle.
+        dense_coarse (batch-shared, plan-cached hierarchies): the last level (<= 128 nodes) gets the inverse of its
+        matrix and is solved by one dense product instead of n_coarse Jacobi sweeps."""
         p, L = self.p, self.L
         st = _stream(p.device)
         chain = [dict(n=p.n, W=p.W, vals=vals, cols=p.cols)]
@@ -440,6 +442,16 @@ class _Engine:
                 if lv.get("p_cols") is not None:      # smoothed aggregation: P as ELL rows, P^T weights
                     arr[i].agg_weights, arr[i].p_cols = lv["agg_weights"].data_ptr(), lv["p_cols"].data_ptr()
                     arr[i].p_vals, arr[i].p_width = lv["p_vals"].data_ptr(), int(lv["p_cols"].shape[0])
+        last = chain[-1]
+        if dense_coarse and Bv == 1 and len(chain) > 1 and last["n"] <= 128 and os.environ.get("DIFFHE_AMG_DENSE", "1") != "0":
+            nc = last["n"]
+            dense = torch.zeros((nc, nc), dtype=torch.float64, device=p.device)
+            rows = torch.arange(nc, device=p.device).repeat(last["W"])
+            dense.index_put_((rows, last["cols"].reshape(-1).long()), last["vals"].reshape(-1), accumulate=True)
+            inv = torch.linalg.inv(dense)
+            if bool(torch.isfinite(inv).all()):
+                last["dense_inv"] = inv.contiguous()
+                arr[len(chain) - 1].dense_inv = last["dense_inv"].data_ptr()
         return arr, chain      # keep `chain` alive: it owns the coarse value tensors
 
     def amg_pcg(self, amg, rhs, Bp, Bv, opts):
@@ -799,7 +811,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
                 amg["scale"] = 1.3 if amg.get("smoothed", 1) else 1.8
             if amg_levels and ell_factored:          # plan-constant hierarchy of the unit operator: built once
                 ctx.amg_hier = plan.unit_amg((smoothed, bool(amg.get("fp32", 0))),
-                                             lambda: eng.amg_setup(vals, 1, bool(amg.get("fp32", 0)), amg_levels))
+                                             lambda: eng.amg_setup(vals, 1, bool(amg.get("fp32", 0)), amg_levels, dense_coarse=True))
             elif amg_levels:                         # at least one coarse level: aggregation-AMG PCG
                 ctx.amg_hier = eng.amg_setup(vals, Bv, bool(amg.get("fp32", 0)), amg_levels)
         if ctx.amg_hier is not None:

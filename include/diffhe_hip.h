@@ -208,6 +208,9 @@ typedef struct diffhe_amg_level {
   const double* p_vals;      /* (p_width, n) */
   int p_width;
   int reserved;
+  /* LAST level of a batch-shared hierarchy (Bv == 1), optional: the (n, n) row-major INVERSE of this level's matrix,
+   * n <= 128 -- the level is then solved by one dense product instead of n_coarse Jacobi sweeps (NULL: sweeps) */
+  const double* dense_inv;
 } diffhe_amg_level;
 
 /* vals_coarse[(k*n_coarse + I)*Bv + b] = sum of weights[c] * vals_fine[contrib[c]*Bv + b], c in ent_ptr[k*n_coarse+I] ..
