@@ -1114,33 +1114,196 @@ struct AmgHier {
   void *xa[kAmgMaxLevels], *xb[kAmgMaxLevels], *res[kAmgMaxLevels], *rhs[kAmgMaxLevels];  // TV vectors
 };
 
+// ---------------------------------------------------------------------------------------
+// Wave-per-node sweep kernels of the solvers (batches of >= 64), SOFTWARE-PIPELINED: with ell_row_uniform inside a plain
+// node loop a wave still paid two dependent memory latencies per node (row meta data -> gathers) for each of its 32
+// nodes, which is what the fine-level sweep's 72-87 us were (32 x 2 x ~1.2 us).  Here the next node's meta data
+// (column indices, shared values, b_i, own x_i) are requested right behind the current node's gathers, so a node costs
+// ONE exposed latency.  Same entries, order and operations as ell_jacobi_kernel / ell_residual_out_kernel /
+// cg_spmv_kernel; same node -> (block, wave) assignment, so the block partials are the same sums.
+//   W_JACOBI: out = x + omega (b - A x) / D, partial of b.out;  W_RESID: out = b - A x;  W_SPMV: out = A x, partial x.out
+// ---------------------------------------------------------------------------------------
+enum { W_JACOBI = 0, W_RESID = 1, W_SPMV = 2 };
+template <int OP, typename TV, typename TM, bool SHARED>
+__global__ __launch_bounds__(256, 8) void ellw_kernel(const TM* __restrict__ vals, const int* __restrict__ cols,
+                                                      const TV* __restrict__ bvec, const TV* __restrict__ xin,
+                                                      TV* __restrict__ out, double omega, double* __restrict__ part,
+                                                      int n, int W, int Bp) {
+  __shared__ double lds[4 * kWave];
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y * kWave + lane;
+  int i, hi, step;
+  wave_node_range(n, i, hi, step);
+  constexpr int NU = SHARED ? 8 : 4;   // per-sample values are vector loads of their own: shorter chunks fit 64 VGPRs
+  const int nk0 = W < kWave ? W : kWave;           // entries of the first (normally the only) 64-entry chunk
+  const i64 lane_ent = (i64)(lane < nk0 ? lane : 0) * n;
+  double s = 0.0;
+  int cv = 0;
+  double av = 0.0;
+  TV bi = (TV)0, xs = (TV)0;
+  if (i < hi) {
+    cv = cols[lane_ent + i];
+    if (SHARED) av = (double)vals[lane_ent + i];
+    if (OP != W_SPMV) bi = bvec[(i64)i * Bp + b];
+    if (OP != W_RESID) xs = xin[(i64)i * Bp + b];
+  }
+  while (i < hi) {
+    const int inext = i + step;
+    double acc = OP == W_SPMV ? 0.0 : (double)bi;
+    double d = 1.0;
+    int cvn = 0;
+    double avn = 0.0;
+    TV bin = (TV)0, xsn = (TV)0;
+    for (int k0 = 0; k0 < W; k0 += kWave) {
+      const int nk = W - k0 < kWave ? W - k0 : kWave;
+      if (k0 > 0) {   // rows wider than 64 entries: not pipelined
+        const i64 e2 = (i64)(k0 + (lane < nk ? lane : 0)) * n + i;
+        cv = cols[e2];
+        if (SHARED) av = (double)vals[e2];
+      }
+      for (int u0 = 0; u0 < nk; u0 += NU) {
+        int c[NU];
+        double a[NU];
+        TV xv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const bool in = u0 + u < nk;
+          const int k = in ? u0 + u : 0;
+          c[u] = __builtin_amdgcn_readlane(cv, k);
+          if (SHARED) a[u] = in ? readlane_f64(av, k) : 0.0;
+        }
+        // (no branches around the loads: a wave-uniform `if` per entry made the compiler wait after every gather;
+        // an absent entry re-reads entry 0 and gets the value 0)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const TV* __restrict__ xr = xin + (i64)c[u] * Bp;
+          xv[u] = xr[b];
+        }
+        if (!SHARED) {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const bool in = u0 + u < nk;
+            const TM* __restrict__ vr = vals + ((i64)(k0 + (in ? u0 + u : 0)) * n + i) * Bp;
+            const double t = (double)vr[b];
+            a[u] = in ? t : 0.0;
+          }
+        }
+        if (k0 == 0 && u0 == 0 && inext < hi) {   // the next node's meta data, behind this node's gathers
+          cvn = cols[lane_ent + inext];
+          if (SHARED) avn = (double)vals[lane_ent + inext];
+          if (OP != W_SPMV) bin = bvec[(i64)inext * Bp + b];
+          if (OP != W_RESID) xsn = xin[(i64)inext * Bp + b];
+        }
+        if (OP == W_JACOBI && k0 == 0 && u0 == 0) d = a[0];   // entry 0 of a row is its diagonal
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (OP == W_SPMV) acc += a[u] * (double)xv[u];
+          else acc -= a[u] * (double)xv[u];
+        }
+      }
+    }
+    const i64 o = (i64)i * Bp + b;
+    if (OP == W_JACOBI) {
+      const double xo = (double)xs + omega * acc / d;
+      out[o] = (TV)xo;
+      s += (double)bi * xo;
+    } else if (OP == W_RESID) {
+      out[o] = (TV)acc;
+    } else {
+      out[o] = (TV)acc;
+      s += acc * (double)xs;
+    }
+    i = inext;
+    cv = cvn; av = avn; bi = bin; xs = xsn;
+  }
+  if (OP != W_RESID && part) {
+    const int wave = threadIdx.x >> 6;
+    const double t = block_sum_per_sample(s, Bp, lds);
+    if (wave == 0) part[(i64)blockIdx.x * Bp + b] = t;
+  }
+}
+// The first sweep of a cycle starts from zero: x = omega b / D, an elementwise pass -- four nodes per trip (one node per
+// trip left a wave with a single load outstanding: 55 us for 134 MB on the fine level of 512^2 x 64).
+template <typename TV, typename TM>
+__global__ __launch_bounds__(256) void ellw_jacobi0_kernel(const TM* __restrict__ vals, const TV* __restrict__ bvec,
+                                                           TV* __restrict__ xout, double omega, int n, int Bp, int Bv) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y * kWave + lane;
+  const int vb = Bv == 1 ? 0 : b;
+  int i, hi, step;
+  wave_node_range(n, i, hi, step);
+  for (; (i64)i + 3LL * step < hi; i += 4 * step) {
+    TV bv[4];
+    double d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bv[u] = bvec[(i64)(i + u * step) * Bp + b];
+      d[u] = (double)vals[(i64)(i + u * step) * Bv + vb];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xout[(i64)(i + u * step) * Bp + b] = (TV)(omega * (double)bv[u] / d[u]);
+  }
+  for (; i < hi; i += step)
+    xout[(i64)i * Bp + b] = (TV)(omega * (double)bvec[(i64)i * Bp + b] / (double)vals[(i64)i * Bv + vb]);
+}
+template <typename TV, typename TM>
+int launch_ellw_jacobi0(const TM* vals, const TV* bvec, TV* xout, double omega, int n, int Bp, int Bv, hipStream_t st) {
+  static const int on = getenv("DIFFHE_ELL_PIPE") ? atoi(getenv("DIFFHE_ELL_PIPE")) : 1;
+  if (!on || Bp < kWave || Bp % kWave) return 0;
+  hipLaunchKernelGGL((ellw_jacobi0_kernel<TV, TM>), diffhe::node_grid(n, Bp), dim3(256), 0, st, vals, bvec, xout, omega, n, Bp, Bv);
+  return 1;
+}
+// launch helper: 1 = launched (batch >= 64, DIFFHE_ELL_PIPE != 0), 0 = caller takes the plain kernel
+template <int OP, typename TV, typename TM>
+int launch_ellw(const TM* vals, const int* cols, const TV* bvec, const TV* xin, TV* out, double omega, double* part, int n,
+                int W, int Bp, int Bv, hipStream_t st) {
+  static const int on = getenv("DIFFHE_ELL_PIPE") ? atoi(getenv("DIFFHE_ELL_PIPE")) : 1;
+  if (!on || Bp < kWave || Bp % kWave) return 0;
+  const dim3 grid = diffhe::node_grid(n, Bp);
+  if (Bv == 1)
+    hipLaunchKernelGGL((ellw_kernel<OP, TV, TM, true>), grid, dim3(256), 0, st, vals, cols, bvec, xin, out, omega, part, n, W, Bp);
+  else
+    hipLaunchKernelGGL((ellw_kernel<OP, TV, TM, false>), grid, dim3(256), 0, st, vals, cols, bvec, xin, out, omega, part, n, W, Bp);
+  return 1;
+}
+
 #define ALAUNCH(kernel, n_, ...) \
   hipLaunchKernelGGL(kernel, diffhe::node_grid((n_), H.Bp), dim3(256), 0, st, __VA_ARGS__)
+
+// Last level of a batch-shared hierarchy: x = A^-1 rhs as ONE dense product with the cached inverse (n <= 128; the 16
+// Jacobi sweeps it replaces were 16 launch-bound launches per cycle and only an approximate solve).  A block = 64
+// samples x 4 rows (one per wave): rhs staged in LDS, a row of the inverse is one vector load.
+template <typename TV>
+__global__ __launch_bounds__(256) void amg_dense_solve_kernel(const double* __restrict__ inv, const TV* __restrict__ rhs,
+                                                               TV* __restrict__ x, int n, int Bp) {
+  extern __shared__ double sm[];   // (n, 64)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int b = blockIdx.x * kWave + lane;
+  const bool ok = b < Bp;
+  for (int j = wave; j < n; j += 4) sm[j * kWave + lane] = ok ? (double)rhs[(i64)j * Bp + b] : 0.0;
+  __syncthreads();
+  const int i = (int)blockIdx.y * 4 + wave;   // one row per wave, four rows per block: the level spreads over n / 4 CUs
+  if (i >= n) return;
+  const double* __restrict__ row = inv + (i64)i * n;
+  double acc = 0.0;
+  for (int j0 = 0; j0 < n; j0 += kWave) {   // 64 entries of the row per vector load, handed out by v_readlane
+    const int nj = n - j0 < kWave ? n - j0 : kWave;
+    const double rv = row[j0 + (lane < nj ? lane : 0)];
+    for (int j = 0; j < nj; j += 8) {   // 8 LDS reads in flight (entries beyond nj: coefficient 0)
+      double sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sv[u] = sm[(j0 + (j + u < nj ? j + u : 0)) * kWave + lane];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fma(j + u < nj ? readlane_f64(rv, j + u) : 0.0, sv[u], acc);
+    }
+  }
+  if (ok) x[(i64)i * Bp + b] = (TV)acc;
+}
 
 // x ~= A_l^{-1} rhs from a zero guess: V(2,2) weighted Jacobi, `gamma` coarse corrections per level
 // (gamma = 2: W-cycle -- affordable because aggregation coarsens by ~10x -- compensates the weak
 // piecewise-constant interpolation).  Returns the buffer holding the result.
-// Last level of a batch-shared hierarchy: x = A^-1 rhs as ONE dense product with the cached inverse (n <= 128; the 16
-// Jacobi sweeps it replaces were 16 launch-bound launches per cycle and only an approximate solve).  A block = 64
-// samples: rhs staged in LDS, each wave takes rows i = wave, wave + 16, ...; the row of the inverse is wave-uniform.
-template <typename TV>
-__global__ __launch_bounds__(1024) void amg_dense_solve_kernel(const double* __restrict__ inv, const TV* __restrict__ rhs,
-                                                                TV* __restrict__ x, int n, int Bp) {
-  extern __shared__ double sm[];   // (n, 64)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
-  const int b = blockIdx.x * kWave + lane;
-  const bool ok = b < Bp;
-  for (int j = wave; j < n; j += nw) sm[j * kWave + lane] = ok ? (double)rhs[(i64)j * Bp + b] : 0.0;
-  __syncthreads();
-  for (int i = wave; i < n; i += nw) {
-    const double* __restrict__ row = inv + (i64)i * n;
-    double acc = 0.0;
-    for (int j = 0; j < n; ++j) acc = fma(row[j], sm[j * kWave + lane], acc);
-    if (ok) x[(i64)i * Bp + b] = (TV)acc;
-  }
-}
-
 template <typename TV>
 TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream_t st) {
   const diffhe_amg_level& L = H.lev[l];
@@ -1148,7 +1311,7 @@ TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream
   TV* b2 = (TV*)H.xb[l];
   const bool last = (l == H.nl - 1);
   if (last && l > 0 && L.dense_inv && H.Bv == 1 && L.n <= 128) {
-    hipLaunchKernelGGL(amg_dense_solve_kernel<TV>, dim3((H.Bp + kWave - 1) / kWave), dim3(1024),
+    hipLaunchKernelGGL(amg_dense_solve_kernel<TV>, dim3((H.Bp + kWave - 1) / kWave, (L.n + 3) / 4), dim3(256),
                        sizeof(double) * L.n * kWave, st, L.dense_inv, rhs, a, L.n, H.Bp);
     return a;
   }
@@ -1157,6 +1320,14 @@ TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream
   const bool m32 = sizeof(TV) == 4 && H.Bv != 1 && L.vals32 != nullptr;
 #define AMG_JACOBI(xin_, xout_, w_, part_)                                                                          \
   do {                                                                                                              \
+    if ((xin_) != nullptr &&                                                                                        \
+        (m32 ? launch_ellw<W_JACOBI, TV, float>(L.vals32, L.cols, rhs, xin_, xout_, w_, part_, L.n, L.W, H.Bp, H.Bv, st) \
+             : launch_ellw<W_JACOBI, TV, double>(L.vals, L.cols, rhs, xin_, xout_, w_, part_, L.n, L.W, H.Bp, H.Bv, st))) \
+      break;                                                                                                        \
+    if ((xin_) == nullptr && (part_) == nullptr &&                                                                  \
+        (m32 ? launch_ellw_jacobi0<TV, float>(L.vals32, rhs, xout_, w_, L.n, H.Bp, H.Bv, st)                         \
+             : launch_ellw_jacobi0<TV, double>(L.vals, rhs, xout_, w_, L.n, H.Bp, H.Bv, st)))                        \
+      break;                                                                                                        \
     if (m32)                                                                                                        \
       ALAUNCH((ell_jacobi_kernel<TV, float>), L.n, L.vals32, L.cols, rhs, xin_, xout_, w_, part_, L.n, L.W, H.Bp, H.Bv); \
     else                                                                                                            \
@@ -1176,7 +1347,11 @@ TV* amg_cycle(const AmgHier& H, int l, const TV* rhs, double* rz_part, hipStream
   const diffhe_amg_level& C = H.lev[l + 1];
   const int cycles = (l + 1 == H.nl - 1) ? 1 : H.gamma;  // the last level is "solved": one visit is enough
   for (int g = 0; g < cycles; ++g) {
-    if (m32)
+    if (m32 ? launch_ellw<W_RESID, TV, float>(L.vals32, L.cols, rhs, (const TV*)a, (TV*)H.res[l], 0.0, nullptr, L.n, L.W,
+                                              H.Bp, H.Bv, st)
+            : launch_ellw<W_RESID, TV, double>(L.vals, L.cols, rhs, (const TV*)a, (TV*)H.res[l], 0.0, nullptr, L.n, L.W,
+                                               H.Bp, H.Bv, st)) {
+    } else if (m32)
       ALAUNCH((ell_residual_out_kernel<TV, float>), L.n, L.vals32, L.cols, rhs, (const TV*)a, (TV*)H.res[l], L.n, L.W,
               H.Bp, H.Bv);
     else
@@ -1537,7 +1712,9 @@ extern "C" int diffhe_ell_amg_pcg_solve(const diffhe_amg_level* levels, int n_le
   if (rc) return rc;
   int it = 0, n_active = -1;
   while (it < max_iter) {
-    hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, (const double*)p, Ap, partA, n, W, Bp, Bv);
+    if (!launch_ellw<W_SPMV, double, double>(L0.vals, L0.cols, (const double*)nullptr, (const double*)p, Ap, 0.0, partA, n, W,
+                                             Bp, Bv, st))
+      hipLaunchKernelGGL(cg_spmv_kernel, grid, dim3(256), 0, st, L0.vals, L0.cols, (const double*)p, Ap, partA, n, W, Bp, Bv);
     ELL_SCALAR(PH_ALPHA, (const double*)partA, (const double*)nullptr);
     hipLaunchKernelGGL(amg_update_kernel, grid, dim3(256), 0, st, (const double*)p, (const double*)Ap,
                        (const double*)S.alpha, x, r, r32, (const double*)S.rs, partC, S.xx ? partD : (double*)nullptr, n, Bp);
