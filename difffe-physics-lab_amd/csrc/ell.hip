@@ -1248,7 +1248,8 @@ __global__ __launch_bounds__(256) void ellw_jacobi0_kernel(const TM* __restrict_
 }
 template <typename TV, typename TM>
 int launch_ellw_jacobi0(const TM* vals, const TV* bvec, TV* xout, double omega, int n, int Bp, int Bv, hipStream_t st) {
-  static const int on = getenv("DIFFHE_ELL_PIPE") ? atoi(getenv("DIFFHE_ELL_PIPE")) : 1;
+  const char* env = getenv("DIFFHE_ELL_PIPE");   // read per launch: a test compares both forms in one process
+  const int on = env ? atoi(env) : 1;
   if (!on || Bp < kWave || Bp % kWave) return 0;
   hipLaunchKernelGGL((ellw_jacobi0_kernel<TV, TM>), diffhe::node_grid(n, Bp), dim3(256), 0, st, vals, bvec, xout, omega, n, Bp, Bv);
   return 1;
@@ -1257,7 +1258,8 @@ int launch_ellw_jacobi0(const TM* vals, const TV* bvec, TV* xout, double omega, 
 template <int OP, typename TV, typename TM>
 int launch_ellw(const TM* vals, const int* cols, const TV* bvec, const TV* xin, TV* out, double omega, double* part, int n,
                 int W, int Bp, int Bv, hipStream_t st) {
-  static const int on = getenv("DIFFHE_ELL_PIPE") ? atoi(getenv("DIFFHE_ELL_PIPE")) : 1;
+  const char* env = getenv("DIFFHE_ELL_PIPE");   // read per launch: a test compares both forms in one process
+  const int on = env ? atoi(env) : 1;
   if (!on || Bp < kWave || Bp % kWave) return 0;
   const dim3 grid = diffhe::node_grid(n, Bp);
   if (Bv == 1)

@@ -938,3 +938,36 @@ def test_strip_form_of_the_per_sample_assembly_is_bitwise_the_node_per_wave_kern
             res.append((v, lf))
         assert bool(torch.isfinite(res[0][0]).all()) and bool(torch.isfinite(res[0][1]).all())
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (nx, ny, flag)
+
+
+@pytest.mark.parametrize("case", ["scalar-per-sample (shared unit matrix, fp32 cycle)", "field-per-sample (per-sample matrices)",
+                                  "field-per-sample, fp32 cycle", "P2 elements (rows of up to 19 entries)"])
+def test_pipelined_wave_per_node_kernels_give_bitwise_the_plain_kernels_answers(case, monkeypatch):
+    """The general path's sweep / residual / CG-product kernels for batches of >= 64 (`ellw_kernel`: a wave per node,
+    column indices by one vector load + readlane, the next node's row data requested behind this node's gathers) take
+    the same entries in the same order with the same operations as the plain kernels, and give each block the same
+    nodes to sum: u, dL/dkappa and dL/df are BITWISE those of DIFFHE_ELL_PIPE=0, for batch-shared and per-sample
+    matrices, fp64- and fp32-stored cycles, 7-entry rows and the wider rows of P2 elements and coarse levels."""
+    gen = torch.Generator().manual_seed(77)
+    B = 64
+    kw = {}
+    if case.startswith("P2"):
+        mesh = FEMesh.rectangle_p2(14, 12, bc_value=0.2)
+        kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+    else:
+        mesh = _unstructured(44, 40, seed=5)
+        if case.startswith("scalar"):
+            kappa = 0.5 + 1.5 * torch.rand(B, generator=gen, dtype=T64)
+        else:
+            kappa = torch.exp(0.4 * torch.randn(B, mesh.n_elements, generator=gen, dtype=T64))
+            if "fp32" in case:
+                kw["amg"] = {"fp32": 1}
+    f = 1 + 0.5 * torch.randn(B, mesh.n_nodes, generator=gen, dtype=T64)
+    res = []
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("DIFFHE_ELL_PIPE", pipe)
+        res.append(_run(mesh, kappa, f, **kw))
+    assert res[0][3].path.startswith("ell-") and res[0][3].not_converged == 0
+    assert res[0][3].iterations == res[1][3].iterations and res[0][3].adj_iterations == res[1][3].adj_iterations
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b), case
