@@ -809,6 +809,16 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
             amg_levels = plan.ensure_amg(smoothed=smoothed)
             if amg.get("scale") is None:
                 amg["scale"] = 1.3 if amg.get("smoothed", 1) else 1.8
+            if amg.get("gamma") is None:      # None = automatic (the default); an explicit 1 or 2 is honoured
+                amg["gamma"] = 1
+                big = smoothed and plan.n * Bp >= 12_000_000
+                # W-cycle where the FINE level dominates the cycle (>= 12 M node-samples): the second visit of the
+                # coarser levels costs latency-bound launches on a few thousand nodes, the fine-level sweeps are the
+                # bill -- 39 -> 24 iterations, 38.3 -> 35.0 ms at jittered 512^2 x 64, 143.6 -> 118.9 ms at 512^2 x 256,
+                # per-sample matrices 102.7 -> 94.8; below that size the V-cycle wins (256^2 x 64: 11.1 against 14.4 ms;
+                # 128^2 x 64: 5.9 against 9.3; gpurun_out/r4be, r4bf)
+                if big:
+                    amg["gamma"] = 2
             if amg_levels and ell_factored:          # plan-constant hierarchy of the unit operator: built once
                 ctx.amg_hier = plan.unit_amg((smoothed, bool(amg.get("fp32", 0))),
                                              lambda: eng.amg_setup(vals, 1, bool(amg.get("fp32", 0)), amg_levels, dense_coarse=True))
@@ -1233,7 +1243,7 @@ class DifferentiableFESolver(nn.Module):
         # Jacobi step of the unit-kappa operator (batch-shared), coarse operators as weighted Galerkin sums per sample:
         # about half the iterations of the piecewise-constant hierarchy (512^2 through this path: 82 -> see DESIGN);
         # scale None = 1.3 smoothed / 1.8 piecewise constant
-        self.amg = dict(n_coarse=16, gamma=1, scale=None, fp32=0, max_iter=20000, smoothed=1)
+        self.amg = dict(n_coarse=16, gamma=None, scale=None, fp32=0, max_iter=20000, smoothed=1)   # gamma None: 1, or 2 on big problems
         for item in filter(None, os.environ.get("DIFFHE_AMG", "").split(",")):  # e.g. "scale=1.0,gamma=2,max_iter=20000"
             key, val = item.split("=")
             self.amg[key] = float(val) if key == "scale" else int(val)
