@@ -1605,6 +1605,10 @@ __device__ __forceinline__ void fused_post_body(const Level& L, VT ib, const flo
   x3_row(r0, a0, a1, a2, u1, b1);
   float* __restrict__ pz = zout + ((i64)r0 * W + c0w) * Bp;
 
+  // (A software-pipelined form of this loop -- the raw loads of the next row requested before this row's two stencil stages,
+  // 48 more live VGPRs, 3 instead of 4 waves per SIMD -- was built and measured at the end of round 4: correct, 168 VGPRs with
+  // 80 B of scratch, 0.999 -> 1.321 ms per fine-level launch, step 80.8 -> 87.5 ms, gpurun_out/r4bj.  Independent waves hide the
+  // row's load latency better than one wave overlapping its own rows.)
   for (int row = r0; row < r1; ++row) {
 #pragma unroll
     for (int j = 0; j < N1; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
