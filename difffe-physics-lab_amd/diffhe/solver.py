@@ -774,7 +774,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
         # solution, residual ratio and adjoint are those of the original one; the aggregation hierarchy and its Galerkin
         # operators are then plan-constant and built once.  Not with a reaction term (kappa_b K_1 + c M is no multiple of
         # one matrix), not for operator="assembled", not with Neumann parts (cond * eps, as on lattices).
-        ell_factored = (mode == K_SAMPLE and reaction == 0.0 and solver.operator != "assembled" and not plan.is_p2
+        ell_factored = (mode in (K_SCALAR, K_SAMPLE) and reaction == 0.0 and solver.operator != "assembled" and not plan.is_p2
                         and solver.method != "ell-jacobi" and plan.closed_boundary_general())
         ctx.ell_inv_kappa = None
         if ell_factored and "fp32" not in solver._amg_user:
@@ -787,7 +787,7 @@ def _solve_forward(solver, kappa, f, load=None, node_major=False):
             vals, lift = eng.assemble(one, 0, 0, 1)
             Bv = 1
             kpad = torch.ones(Bp, dtype=torch.float64, device=plan.device)
-            kpad[:B] = kappa.detach().to(plan.device, torch.float64).reshape(B)
+            kpad[:B] = kappa.detach().to(plan.device, torch.float64).reshape(-1)      # (B,), or one scalar for all
             ctx.ell_inv_kappa = 1.0 / kpad
             f_nm = _as_node_major(eng, f_dev, B, Bp, n, node_major)
             rhs = eng.load_vector(f_nm, lift, 1, Bp, kpad)          # F_b = M f_b - kappa_b lift_1

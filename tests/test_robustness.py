@@ -971,3 +971,26 @@ def test_pipelined_wave_per_node_kernels_give_bitwise_the_plain_kernels_answers(
     assert res[0][3].iterations == res[1][3].iterations and res[0][3].adj_iterations == res[1][3].adj_iterations
     for a, b in zip(res[0][:3], res[1][:3]):
         assert torch.equal(a, b), case
+
+
+def test_general_path_keeps_one_scalar_kappa_factored_too():
+    """kappa = one scalar for the whole batch (the reference's default call) on a closed unstructured mesh: the same factored
+    form as one scalar per sample -- the unit matrix, its plan-cached hierarchy, K_1 x = F / kappa -- instead of a matrix
+    that carries kappa and a Galerkin product per solve.  Same answers as operator='assembled', the oracle met, the
+    gradient a scalar."""
+    mesh = _unstructured(40, 36, seed=11)
+    B, n = 64, mesh.n_nodes
+    gen = torch.Generator().manual_seed(5)
+    kappa = torch.tensor(1.7, dtype=T64)
+    f = 1 + 0.5 * torch.randn(B, n, generator=gen, dtype=T64)
+    fac = _run(mesh, kappa, f)
+    per = _run(mesh, kappa, f, operator="assembled")
+    assert fac[3].path == "ell-amgpcg" and fac[3].factored and not per[3].factored
+    assert fac[1].shape == kappa.shape and fac[3].not_converged == 0
+    for a, b in zip(fac[:3], per[:3]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-11
+    bn, bv = np.array(list(mesh.dirichlet_nodes.keys())), np.array(list(mesh.dirichlet_nodes.values()))
+    uo, dk, df = orc.solve_with_adjoint(mesh.nodes.numpy(), mesh.elements.numpy(), bn, bv, 1.7, f[3].numpy(),
+                                        lambda u_: 2 * u_, sparse=True, refine=1)
+    assert rel_err(fac[0][3].cpu().numpy(), uo) < RTOL_U
+    assert rel_err(fac[2][3].cpu().numpy(), df) < RTOL_GRAD
