@@ -1222,6 +1222,9 @@ __global__ __launch_bounds__(256, 8) void ellw_kernel(const TM* __restrict__ val
     if (wave == 0) part[(i64)blockIdx.x * Bp + b] = t;
   }
 }
+// (A two-samples-per-lane form of ellw_kernel for batch-shared matrices and batches of 128 k -- 8 / 16-byte gathers, the
+// node's scalar work paid once per 128 samples -- was built and measured: bitwise the same values, 117.0 -> 116.0 ms per
+// solve at jittered 512^2 x 256, gpurun_out/r4bn.  The sweeps are not instruction-bound; removed.)
 // The first sweep of a cycle starts from zero: x = omega b / D, an elementwise pass -- four nodes per trip (one node per
 // trip left a wave with a single load outstanding: 55 us for 134 MB on the fine level of 512^2 x 64).
 template <typename TV, typename TM>
