@@ -942,15 +942,15 @@ def test_strip_form_of_the_per_sample_assembly_is_bitwise_the_node_per_wave_kern
 
 @pytest.mark.parametrize("case", ["scalar-per-sample (shared unit matrix, fp32 cycle)", "field-per-sample (per-sample matrices)",
                                   "field-per-sample, fp32 cycle", "P2 elements (rows of up to 19 entries)",
-                                  "scalar-per-sample, batch of 128 (two samples per lane)",
-                                  "scalar-per-sample, batch of 128, fp64 cycle (two samples per lane)"])
+                                  "scalar-per-sample, batch of 128",
+                                  "scalar-per-sample, batch of 128, fp64 cycle"])
 def test_pipelined_wave_per_node_kernels_give_bitwise_the_plain_kernels_answers(case, monkeypatch):
     """The general path's sweep / residual / CG-product kernels for batches of >= 64 (`ellw_kernel`: a wave per node,
     column indices by one vector load + readlane, the next node's row data requested behind this node's gathers) take
     the same entries in the same order with the same operations as the plain kernels, and give each block the same
     nodes to sum: u, dL/dkappa and dL/df are BITWISE those of DIFFHE_ELL_PIPE=0, for batch-shared and per-sample
-    matrices, fp64- and fp32-stored cycles, 7-entry rows and the wider rows of P2 elements and coarse levels, one and
-    (batches of 128, `ellw2_kernel`) two samples per lane."""
+    matrices, fp64- and fp32-stored cycles, 7-entry rows and the wider rows of P2 elements and coarse levels, batches of one
+    and two waves of samples."""
     gen = torch.Generator().manual_seed(77)
     B = 128 if "128" in case else 64
     kw = {"amg": {"fp32": 0}} if "fp64 cycle" in case else {}
