@@ -792,19 +792,24 @@ __global__ __launch_bounds__(256) void to_node_major_kernel(const double* __rest
   __shared__ double tile[kT][kT + 1];
   const int i0 = blockIdx.x * kT, b0 = blockIdx.y * kT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int bb = wave; bb < kT; bb += 4) {  // lanes along i: coalesced reads of a sample row
-    const int b = b0 + bb, i = i0 + lane;
-    double v = 0.0;
-    if (b < B && i < n) v = src[(i64)b * ld + i];
-    tile[bb][lane] = v;
+  // the 16 rows of a wave are loaded into registers first (16 loads in flight; a load-store loop had one), then staged
+  double v[kT / 4];
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) {  // lanes along i: coalesced reads of a sample row
+    const int b = b0 + wave + 4 * k, i = i0 + lane;
+    v[k] = (b < B && i < n) ? src[(i64)b * ld + i] : 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) tile[wave + 4 * k][lane] = v[k];
   __syncthreads();
-  for (int ii = wave; ii < kT; ii += 4) {  // lanes along b: coalesced writes of a node row
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) {  // lanes along b: coalesced writes of a node row
+    const int ii = wave + 4 * k;
     const int i = i0 + ii, b = b0 + lane;
     if (i < n && b < Bp) {
-      double v = tile[lane][ii];
-      if (zero_mask && zero_mask[i]) v = 0.0;
-      dst[(i64)i * Bp + b] = v;
+      double w = tile[lane][ii];
+      if (zero_mask && zero_mask[i]) w = 0.0;
+      dst[(i64)i * Bp + b] = w;
     }
   }
 }
@@ -815,14 +820,18 @@ __global__ __launch_bounds__(256) void to_sample_major_kernel(const double* __re
   __shared__ double tile[kT][kT + 1];
   const int i0 = blockIdx.x * kT, b0 = blockIdx.y * kT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int ii = wave; ii < kT; ii += 4) {
-    const int i = i0 + ii, b = b0 + lane;
-    double v = 0.0;
-    if (i < n && b < Bp) v = src[(i64)i * Bp + b] + (add ? add[i] : 0.0);
-    tile[ii][lane] = v;
+  double v[kT / 4];
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) {   // 16 node rows per wave, all requested before the first is staged
+    const int i = i0 + wave + 4 * k, b = b0 + lane;
+    v[k] = (i < n && b < Bp) ? src[(i64)i * Bp + b] + (add ? add[i] : 0.0) : 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) tile[wave + 4 * k][lane] = v[k];
   __syncthreads();
-  for (int bb = wave; bb < kT; bb += 4) {
+#pragma unroll
+  for (int k = 0; k < kT / 4; ++k) {
+    const int bb = wave + 4 * k;
     const int b = b0 + bb, i = i0 + lane;
     if (b < B && i < n) dst[(i64)b * ld + i] = tile[lane][bb];
   }
