@@ -164,7 +164,7 @@ def pin_rank(world, local_rank):
             os.sched_setaffinity(0, cpus)
         return {"cores": len(cpus), "first": min(cpus) if cpus else None,
                 "numa_node": numa[local_rank] if local_rank < len(numa) else None}
-    except (OSError, ValueError, AttributeError) as exc:
+    except Exception as exc:   # noqa: BLE001 -- placement is an optimisation: whatever goes wrong, the rank runs unpinned
         return {"error": type(exc).__name__}
 
 
