@@ -449,6 +449,7 @@ class _Engine:
             rows = torch.arange(nc, device=p.device).repeat(last["W"])
             dense.index_put_((rows, last["cols"].reshape(-1).long()), last["vals"].reshape(-1), accumulate=True)
             inv = torch.linalg.inv(dense)
+            inv = 0.5 * (inv + inv.t())            # symmetric to the last bit: the cycle stays a symmetric preconditioner
             if bool(torch.isfinite(inv).all()):
                 last["dense_inv"] = inv.contiguous()
                 arr[len(chain) - 1].dense_inv = last["dense_inv"].data_ptr()
